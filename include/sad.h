@@ -1,0 +1,161 @@
+/* libsad — C-ABI of the MI355X-native self-attention style discriminator (hot path only).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  The
+ * reference has no FFI for this path (it is pure PyTorch); each entry point below cites the
+ * reference Python lines whose arithmetic it replaces (paths relative to the reference repo).
+ * The host-side mirror of the reference interface (`SelfAttnRNNClassifier`, same constructor /
+ * forward / state_dict) lives in the Python package and binds these symbols with ctypes; see
+ * INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     asynchronously on it, nothing here synchronises or allocates;
+ *   - functions return 0 on success, <0 on error; `sad_last_error()` (thread-local, host string)
+ *     describes the last failure of the calling thread;
+ *   - token rows are addressed through explicit element strides, so both the transfer loop's
+ *     time-major soft tokens ([T,B,V] storage viewed as [B,T,V]) and batch-major tensors work
+ *     without copies; the vocabulary axis must be contiguous.
+ */
+#ifndef SAD_H_
+#define SAD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAD_VERSION 100 /* 0.1.0 */
+
+/* src_kind / dsrc_kind */
+#define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
+#define SAD_SRC_F32 1  /* fp32 soft tokens [B,T,V]               (reference: src @ embedding.weight) */
+#define SAD_SRC_BF16 2 /* bf16 soft tokens [B,T,V] */
+
+typedef struct sad_dims {
+    int32_t B; /* sentences in this call */
+    int32_t T; /* max length incl. sos/eos (<= 1024) */
+    int32_t V; /* vocabulary */
+    int32_t E; /* embedding size */
+    int32_t H; /* LSTM hidden size per direction */
+    int32_t L; /* labels (<= 64) */
+} sad_dims;
+
+/* The reference module's fp32 parameters (state_dict layout, reference transfer/models.py:757-829;
+ * output_bridge.* and hidden_bridges.1.* never reach the logits and are not needed). Index 0 =
+ * forward direction (`*_l0`), 1 = reverse (`*_l0_reverse`). */
+typedef struct sad_weights {
+    const float* embedding_weight;       /* [V,E]  */
+    const float* rnn_weight_ih[2];       /* [4H,E] */
+    const float* rnn_weight_hh[2];       /* [4H,H] */
+    const float* rnn_bias_ih[2];         /* [4H]   */
+    const float* rnn_bias_hh[2];         /* [4H]   */
+    const float* hidden_bridge0_weight;  /* [H,2H] */
+    const float* hidden_bridge0_bias;    /* [H]    */
+    const float* linear_emb_weight;      /* [H,E]  */
+    const float* linear_emb_bias;        /* [H]    */
+    const float* linear_q_weight;        /* [H,H]  */
+    const float* linear_q_bias;          /* [H]    */
+    const float* linear_attn_weight;     /* [1,H]  */
+    const float* linear_attn_bias;       /* [1]    */
+    const float* output_layer_weight;    /* [L,H]  */
+    const float* output_layer_bias;      /* [L]    */
+} sad_weights;
+
+typedef struct sad_fwd_args {
+    const void* src;          /* ids / soft tokens, see src_kind */
+    int32_t src_kind;
+    int64_t src_stride_b;     /* element strides of the batch and time axes */
+    int64_t src_stride_t;
+    const int32_t* lengths;   /* [B], sentence lengths incl. sos/eos */
+    uint8_t* mask;            /* [B,T] bool bytes, 1 = pad/sos/eos; MUTATED in place when guard != 0 */
+    int64_t mask_stride_b;
+    int64_t mask_stride_t;
+    int32_t guard;            /* 1: transfer copy (all-masked rows get position 1 unmasked,
+                                 reference transfer/models.py:865-867); 0: classifier copy */
+    const int64_t* labels;    /* [B] or NULL; with `loss` gives per-sentence CE */
+    float* logits;            /* out [B,L] */
+    float* weights;           /* out [B,T] attention weights */
+    float* loss;              /* out [B] or NULL */
+} sad_fwd_args;
+
+typedef struct sad_bwd_args {
+    const float* dlogits;     /* [B,L] upstream gradient of the logits, or NULL to use CE: */
+    const int64_t* labels;    /*   [B] labels and                                            */
+    const float* dloss;       /*   [B] upstream gradient of the per-sentence loss, or NULL -> */
+    float dloss_scale;        /*   this scalar for every sentence (1/B for `.mean()`)         */
+    const float* dweights;    /* [B,T] upstream gradient of the attention weights, or NULL */
+    const float* logits;      /* [B,L] as written by sad_forward */
+    const float* weights;     /* [B,T] as written by sad_forward */
+    void* dsrc;               /* out: d(soft tokens) in dsrc_kind (F32/BF16) and strides, or NULL */
+    int32_t dsrc_kind;
+    int64_t dsrc_stride_b;
+    int64_t dsrc_stride_t;
+} sad_bwd_args;
+
+/* Named regions of the workspace, for tests / profiling (sad_workspace_field). */
+enum sad_ws_field {
+    SAD_WS_LENS = 0, /* int32 [B] clamped lengths */
+    SAD_WS_NEED,     /* u8   [T*B] */
+    SAD_WS_X,        /* bf16 [T*B][Ep] */
+    SAD_WS_G,        /* fp32 [T*B][2][Gp] activated gates, permuted columns */
+    SAD_WS_CS,       /* fp32 [T*B][2][Hp] */
+    SAD_WS_HS,       /* bf16 [T*B][2][Hp] */
+    SAD_WS_KK,       /* fp32 [T*B][Hp] */
+    SAD_WS_Q,        /* fp32 [B][Hp] */
+    SAD_WS_U,        /* fp32 [B][Hp] */
+    SAD_WS_CTX,      /* fp32 [B][Hp] */
+    SAD_WS_DZ,       /* bf16 [T*B][Ncat] */
+    SAD_WS_DX,       /* bf16 [T*B][Ep] */
+    SAD_WS_DU,       /* fp32 [B][Hp] */
+    SAD_WS_DQ,       /* fp32 [B][Hp] */
+    SAD_WS_DHFIN,    /* fp32 [B][2][Hp] */
+    SAD_WS_DC,       /* fp32 [B][2][Hp] */
+    SAD_WS_NFIELDS
+};
+
+int sad_version(void);
+const char* sad_last_error(void);
+
+/* Padded sizes derived from dims: out[0..4] = Ep, Hp, Gp, Vp, Ncat. */
+int sad_padded_dims(const sad_dims* d, int32_t out[5]);
+
+/* Bytes of the packed (bf16, padded, gate-permuted, pre-transposed) weight image. */
+size_t sad_packed_bytes(const sad_dims* d);
+/* Bytes of the per-call workspace (saved activations + backward scratch). 256-byte aligned base. */
+size_t sad_workspace_bytes(const sad_dims* d);
+int sad_workspace_field(const sad_dims* d, int field, size_t* offset, size_t* bytes);
+
+/* state_dict fp32 -> packed image.  Replaces nothing in the reference (it consumes fp32 parameters
+ * directly, transfer/models.py:770-827); call again whenever the parameters change. */
+int sad_pack_weights(const sad_dims* d, const sad_weights* w, void* packed, void* stream);
+
+/* SelfAttnRNNClassifier.forward (reference transfer/models.py:885-953 incl. attention :841-883;
+ * classifier copy classifier/models.py:200-266 with guard = 0) + per-sentence
+ * nn.CrossEntropyLoss(reduction='none') (transfer/models.py:990,1212) when labels/loss are given.
+ * Saves what the backward needs in `workspace`. */
+int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* workspace, void* stream);
+
+/* Autograd backward of the above down to d(soft tokens) with frozen parameters — what
+ * loss.backward() (reference transfer/trainers.py:376) runs through transfer/models.py:1185-1187.
+ * `workspace` must be the one the matching sad_forward filled. */
+int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* workspace, void* stream);
+
+/* Single stages, for unit tests and for timing the dominant kernels in isolation (bench.py).
+ * sad_prep: length clamp + mask guard + need bits (reference transfer/models.py:865-867).
+ * sad_softemb_fwd:  X = S @ W_emb            (reference transfer/models.py:898), S -> workspace X.
+ * sad_softemb_bwd:  dS = dX @ W_emb^T        (its autograd), workspace DX -> dsrc.
+ * Both read the need bits a previous sad_prep / sad_forward left in `workspace`. */
+int sad_prep(const sad_dims* d, const int32_t* lengths, uint8_t* mask, int64_t mask_stride_b,
+             int64_t mask_stride_t, int32_t guard, void* workspace, void* stream);
+int sad_softemb_fwd(const sad_dims* d, const void* packed, const void* src, int32_t src_kind,
+                    int64_t src_stride_b, int64_t src_stride_t, void* workspace, void* stream);
+int sad_softemb_bwd(const sad_dims* d, const void* packed, void* dsrc, int32_t dsrc_kind,
+                    int64_t dsrc_stride_b, int64_t dsrc_stride_t, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAD_H_ */

@@ -1,0 +1,2 @@
+"""``getattr(models, "SelfAttnRNNClassifier")`` target mirroring reference classifier/models.py."""
+from .models import ClassifierSelfAttnRNNClassifier as SelfAttnRNNClassifier  # noqa: F401

@@ -1,0 +1,89 @@
+// Common device/host definitions for libsad (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sad {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // dword-aligned 16-B access
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4h __attribute__((ext_vector_type(4), aligned(2)));  // 2-byte-aligned 16-B access
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2h __attribute__((ext_vector_type(2), aligned(2)));  // 2-byte-aligned 8-B access
+typedef unsigned short bf16raw;                                           // bf16 bit pattern in memory
+
+__host__ __device__ constexpr int ceil_to(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ constexpr int ceil_div(int x, int m) { return (x + m - 1) / m; }
+
+// Derived (padded) sizes.  Time-major token row m = t*B + b.
+struct Shape {
+    int B, T, V, E, H, L;
+    int Ep;    // E rounded up to 32   (K of the in-projection, N of the soft-embedding GEMM)
+    int Hp;    // H rounded up to 32   (K of the recurrent GEMM; unit dimension)
+    int Gp;    // 4*Hp                 (permuted gate columns per direction)
+    int Vp;    // V rounded up to 64   (K of the soft-embedding GEMM, rows of the packed embedding)
+    int Ncat;  // 2*Gp + Hp            (fused in-projection columns: fwd gates | rev gates | attention keys)
+    int M;     // T*B token rows
+};
+
+__host__ __device__ inline Shape make_shape(int B, int T, int V, int E, int H, int L) {
+    Shape s;
+    s.B = B; s.T = T; s.V = V; s.E = E; s.H = H; s.L = L;
+    s.Ep = ceil_to(E, 32);
+    s.Hp = ceil_to(H, 32);
+    s.Gp = 4 * s.Hp;
+    s.Vp = ceil_to(V, 64);
+    s.Ncat = 2 * s.Gp + s.Hp;
+    s.M = T * B;
+    return s;
+}
+
+// Gate-column permutation: packed column pc = ub*64 + gate*16 + u  <->  torch row gate*H + ub*16 + u
+// (torch gate order i,f,g,o).  One 64-column block holds all four gates of 16 hidden units, so the
+// 16x16 MFMA tiles tn = 0..3 of a wave are the four gates of the SAME units.
+__host__ __device__ inline int gate_col(int unit, int gate) { return (unit >> 4) * 64 + gate * 16 + (unit & 15); }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) {
+    u32x2 r;
+    r[0] = pack_bf16x2(v[0], v[1]);
+    r[1] = pack_bf16x2(v[2], v[3]);
+    return r;
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(f32x4 a, f32x4 b) {
+    u32x4 r;
+    r[0] = pack_bf16x2(a[0], a[1]);
+    r[1] = pack_bf16x2(a[2], a[3]);
+    r[2] = pack_bf16x2(b[0], b[1]);
+    r[3] = pack_bf16x2(b[2], b[3]);
+    return r;
+}
+__device__ __forceinline__ float bf16_to_f32(bf16raw x) { return __builtin_bit_cast(float, (unsigned)x << 16); }
+__device__ __forceinline__ bf16raw f32_to_bf16(float f) { return __builtin_bit_cast(bf16raw, (__bf16)f); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif
+
+}  // namespace sad

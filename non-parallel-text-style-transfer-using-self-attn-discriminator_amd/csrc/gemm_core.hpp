@@ -1,0 +1,111 @@
+// LDS-tiled bf16 MFMA GEMM core for gfx950:  C[m][n] = sum_k A[m][k] * Bt[n][k]   ("NT": both
+// operands K-contiguous, which is the natural layout of torch Linear/LSTM weights [out,in]).
+//
+//  * 64-wide wavefronts, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//  * The MFMA is issued with the operands SWAPPED (Bt fragment as the A operand, A fragment as the
+//    B operand), so the accumulator holds C^T: lane l owns output row  m = l & 15  and the FOUR
+//    CONSECUTIVE columns n = (l >> 4) * 4 + {0..3} of each 16x16 tile.  Epilogues therefore store
+//    8/16 contiguous bytes per lane along n, and the LSTM epilogue finds the four gates of one
+//    hidden unit in acc[tm][0..3] of the same lane (see gate_col()).
+//  * global -> register -> LDS staging, split so the next tile's global loads are in flight while
+//    the MFMAs of the current tile run; LDS rows padded by 16 B (row stride 144 B).
+//  * Operand access goes through loader functors so each op decides dtype conversion (fp32 soft
+//    tokens -> bf16), row predicates (sequence length masks), gathers and bounds.
+#pragma once
+#include "common.hpp"
+
+namespace sad {
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = 64, WM = WM_, WN = WN_;
+    static constexpr int NT = 64 * WM_ * WN_;               // threads per workgroup
+    static constexpr int TM = BM_ / WM_ / 16;               // 16x16 tiles per wave along m
+    static constexpr int TN = BN_ / WN_ / 16;               // ... along n
+    static constexpr int LDT = BK + 8;                      // LDS row stride, bf16 elements
+    static constexpr int CH = BK / 8;                       // 16-byte chunks per tile row
+    static constexpr int RSTEP = NT / CH;                   // tile rows covered per staging pass
+    static constexpr int ACH = BM_ * CH / NT;               // A chunks per thread
+    static constexpr int BCH = BN_ * CH / NT;               // B chunks per thread
+    static_assert(BM_ % (WM_ * 16) == 0 && BN_ % (WN_ * 16) == 0, "tile/wave mismatch");
+    static_assert((BM_ * CH) % NT == 0 && (BN_ * CH) % NT == 0, "staging must divide evenly");
+};
+
+// Row (within the block tile) and first column of this lane's 4-column group for tile (tm, tn).
+template <class C>
+__device__ __forceinline__ int frag_row(int wm, int tm, int lane) { return wm * (C::BM / C::WM) + tm * 16 + (lane & 15); }
+template <class C>
+__device__ __forceinline__ int frag_col(int wn, int tn, int lane) { return wn * (C::BN / C::WN) + tn * 16 + (lane >> 4) * 4; }
+
+// load_a(i, r, k) -> ARaw : chunk i of this thread = tile row r, 8 elements starting at absolute k
+// cvt_a(ARaw)     -> u32x4 (8 bf16)
+// load_b(i, r, k) -> u32x4
+template <class C, class ARaw, class LA, class CA, class LB>
+__device__ __forceinline__ void gemm_core(int K, LA load_a, CA cvt_a, LB load_b,
+                                          f32x4 (&acc)[C::TM][C::TN], bf16raw* As, bf16raw* Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int r0 = tid / C::CH, kc = (tid % C::CH) * 8;
+    ARaw ra[C::ACH];
+    u32x4 rb[C::BCH];
+    const int nk = (K + C::BK - 1) / C::BK;
+
+#pragma unroll
+    for (int i = 0; i < C::ACH; ++i) ra[i] = load_a(i, r0 + i * C::RSTEP, kc);
+#pragma unroll
+    for (int i = 0; i < C::BCH; ++i) rb[i] = load_b(i, r0 + i * C::RSTEP, kc);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();   // every wave is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i)
+            *(u32x4*)&As[(r0 + i * C::RSTEP) * C::LDT + kc] = cvt_a(ra[i]);
+#pragma unroll
+        for (int i = 0; i < C::BCH; ++i)
+            *(u32x4*)&Bs[(r0 + i * C::RSTEP) * C::LDT + kc] = rb[i];
+        __syncthreads();
+        if (kt + 1 < nk) {   // next tile's global loads fly under this tile's MFMAs
+            const int k0 = (kt + 1) * C::BK + kc;
+#pragma unroll
+            for (int i = 0; i < C::ACH; ++i) ra[i] = load_a(i, r0 + i * C::RSTEP, k0);
+#pragma unroll
+            for (int i = 0; i < C::BCH; ++i) rb[i] = load_b(i, r0 + i * C::RSTEP, k0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < C::BK / 32; ++kk) {
+            bf16x8 af[C::TM], bfr[C::TN];
+            const int ko = kk * 32 + (lane >> 4) * 8;
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+                af[tm] = *(const bf16x8*)&As[frag_row<C>(wm, tm, lane) * C::LDT + ko];
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bfr[tn] = *(const bf16x8*)&Bs[(wn * (C::BN / C::WN) + tn * 16 + (lane & 15)) * C::LDT + ko];
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
+        }
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[C::TM][C::TN]) {
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Aligned 16-byte load of 8 bf16 from a packed (padded, 16-B aligned) matrix; zero outside [rows) x [K).
+__device__ __forceinline__ u32x4 load_packed(const bf16raw* base, long long ld, int row, int rows, int k, int K) {
+    if (row < rows && k < K) return *(const u32x4*)(base + (long long)row * ld + k);
+    return u32x4{0u, 0u, 0u, 0u};
+}
+
+struct Ident {
+    __device__ __forceinline__ u32x4 operator()(u32x4 v) const { return v; }
+};
+
+}  // namespace sad

@@ -1,0 +1,763 @@
+// Hand-written gfx950 kernels of the discriminator hot path.  Reference lines each kernel replaces
+// (paths relative to the reference repo) are cited at the kernel.
+//
+// Buffers (all time-major, token row m = t*B + b; see DESIGN.md "Data layout in HBM"):
+//   need [M]           u8    bit0: t < len[b] (LSTM-active), bit1: !mask'[b,t] (attention-active)
+//   X    [M][Ep]       bf16  embedded tokens
+//   G    [M][2][Gp]    fp32  gate pre-activations (input part) -> overwritten by activated i,f,g,o
+//   Cs   [M][2][Hp]    fp32  cell state after step t
+//   Hs   [M][2][Hp]    bf16  hidden state after step t (MFMA operand of the next step)
+//   Kk   [M][Hp]       fp32  attention keys/values  linear_emb(X)
+//   DZ   [M][Ncat]     bf16  d(pre-activations): [fwd gates | rev gates | dKk]
+//   DX   [M][Ep]       bf16  d(embedded tokens)
+#pragma once
+#include "gemm_core.hpp"
+
+namespace sad {
+
+enum { SRC_IDS = 0, SRC_F32 = 1, SRC_BF16 = 2 };
+
+// ------------------------------------------------------------------------------------------------
+// prep: clamp lengths, apply the all-masked-row guard IN PLACE on the caller's mask
+// (transfer/models.py:865-867), derive the per-token need bits.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prep(Shape s, const int* __restrict__ lens_in, unsigned char* mask, long long msb, long long mst,
+                       int guard, unsigned char* __restrict__ need, int* __restrict__ lens) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= s.B) return;
+    int len = lens_in[b];
+    len = len < 0 ? 0 : (len > s.T ? s.T : len);
+    lens[b] = len;
+    unsigned char* mrow = mask + (long long)b * msb;
+    if (guard && s.T > 1) {
+        bool all = true;
+        for (int t = 0; t < s.T; ++t) all = all && (mrow[(long long)t * mst] != 0);
+        if (all) mrow[mst] = 0;
+    }
+    for (int t = 0; t < s.T; ++t)
+        need[(long long)t * s.B + b] = (unsigned char)((t < len ? 1 : 0) | (mrow[(long long)t * mst] ? 0 : 2));
+}
+
+template <class C>
+__device__ __forceinline__ int tile_any_need(const unsigned char* __restrict__ need, int m0, int M) {
+    int any = 0;
+    for (int r = threadIdx.x; r < C::BM; r += C::NT) {
+        const int m = m0 + r;
+        if (m < M && need[m]) any = 1;
+    }
+    return __syncthreads_or(any);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  soft-embedding contraction  X[m][e] = sum_v S[m][v] * W_emb[v][e]   (transfer/models.py:898)
+// S is read ONCE from HBM (fp32 or bf16, V-contiguous rows at arbitrary (t,b) strides, rows only
+// 4-/2-byte aligned because V is odd) and converted to bf16 on the way into LDS.
+// ------------------------------------------------------------------------------------------------
+struct RawF32x8 {
+    f32x4 lo, hi;
+};
+struct CvtF32x8 {
+    __device__ __forceinline__ u32x4 operator()(const RawF32x8& r) const { return pack_bf16x8(r.lo, r.hi); }
+};
+
+template <int KIND>
+struct SoftRow;   // loads 8 consecutive vocabulary entries of one token row
+template <>
+struct SoftRow<SRC_F32> {
+    typedef RawF32x8 Raw;
+    typedef CvtF32x8 Cvt;
+    typedef float Elem;
+    static __device__ __forceinline__ Raw load(const float* p, int k, int V) {
+        Raw r;
+        if (p != nullptr && k + 8 <= V) {
+            r.lo = *(const f32x4u*)(p + k);
+            r.hi = *(const f32x4u*)(p + k + 4);
+        } else {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (p != nullptr && k + j < V) ? p[k + j] : 0.f;
+            r.lo = f32x4{t[0], t[1], t[2], t[3]};
+            r.hi = f32x4{t[4], t[5], t[6], t[7]};
+        }
+        return r;
+    }
+};
+template <>
+struct SoftRow<SRC_BF16> {
+    typedef u32x4 Raw;
+    typedef Ident Cvt;
+    typedef bf16raw Elem;
+    static __device__ __forceinline__ Raw load(const bf16raw* p, int k, int V) {
+        if (p != nullptr && k + 8 <= V) return *(const u32x4h*)(p + k);
+        unsigned t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (p != nullptr && k + j < V) ? (unsigned)p[k + j] : 0u;
+        return u32x4{t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16)};
+    }
+};
+
+template <class C, int KIND>
+__global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __restrict__ src, long long sT, long long sB,
+                                                      const unsigned char* __restrict__ need,
+                                                      const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X) {
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    typedef SoftRow<KIND> SR;
+    typedef typename SR::Elem Elem;
+    const int m0 = blockIdx.x * C::BM, n0 = blockIdx.y * C::BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    if (tile_any_need<C>(need, m0, s.M)) {
+        const Elem* arow[C::ACH];
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) {
+            const int m = m0 + tid / C::CH + i * C::RSTEP;
+            arow[i] = nullptr;
+            if (m < s.M) {
+                const int t = m / s.B, b = m - t * s.B;
+                arow[i] = (const Elem*)src + (long long)t * sT + (long long)b * sB;
+            }
+        }
+        const int V = s.V, Vp = s.Vp, Ep = s.Ep;
+        gemm_core<C, typename SR::Raw>(
+            V, [&](int i, int, int k) { return SR::load(arow[i], k, V); }, typename SR::Cvt(),
+            [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, k, Vp); }, acc, As, Bs);
+    }
+    const int wm = wave / C::WN, wn = wave % C::WN;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = n0 + frag_col<C>(wn, tn, lane);
+            if (m < s.M && n < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
+        }
+    }
+}
+
+// Hard tokens: X[m] = bf16(W_emb[ids[b,t]])  (transfer/models.py:900).  One 16-byte chunk per thread.
+__global__ void k_embed_gather(Shape s, const long long* __restrict__ ids, long long ib, long long it,
+                               const bf16raw* __restrict__ wemb, bf16raw* __restrict__ X) {
+    const int cpr = s.Ep / 8;
+    const long long total = (long long)s.M * cpr;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(c / cpr), kc = (int)(c - (long long)m * cpr) * 8;
+        const int t = m / s.B, b = m - t * s.B;
+        const long long id = ids[(long long)b * ib + (long long)t * it];
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (id >= 0 && id < s.V) v = *(const u32x4*)(wemb + id * s.Ep + kc);
+        *(u32x4*)(X + (long long)m * s.Ep + kc) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a + K3  fused input projection:  [G | Kk][m] = X[m] . Wcat^T + bcat
+// (nn.LSTM input GEMMs of both directions, transfer/models.py:779-785,906, and linear_emb, :925)
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::NT) void k_inproj_fwd(Shape s, const bf16raw* __restrict__ X,
+                                                     const unsigned char* __restrict__ need,
+                                                     const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
+                                                     float* __restrict__ G, float* __restrict__ Kk) {
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    const int n0 = blockIdx.x * C::BN, m0 = blockIdx.y * C::BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!tile_any_need<C>(need, m0, s.M)) return;   // rows nobody reads (t >= len and masked)
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    const int Ep = s.Ep, M = s.M, Ncat = s.Ncat;
+    gemm_core<C, u32x4>(
+        Ep, [&](int, int r, int k) { return load_packed(X, Ep, m0 + r, M, k, Ep); }, Ident(),
+        [&](int, int r, int k) { return load_packed(wcat, Ep, n0 + r, Ncat, k, Ep); }, acc, As, Bs);
+    const int wm = wave / C::WN, wn = wave % C::WN, G2 = 2 * s.Gp;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = n0 + frag_col<C>(wn, tn, lane);
+            if (m < M && n < Ncat) {
+                const f32x4 v = acc[tm][tn] + *(const f32x4*)&bcat[n];
+                if (n < G2)
+                    *(f32x4*)&G[(long long)m * G2 + n] = v;
+                else
+                    *(f32x4*)&Kk[(long long)m * s.Hp + (n - G2)] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2b  one time step of the bidirectional LSTM recurrence (both directions in one launch):
+//   gates = G[t] + h_prev . W_hh^T ; i,f,o = sigmoid, g = tanh ; c = f*c_prev + i*g ; h = o*tanh(c)
+// Only rows with t < len[b] are touched (packed-sequence semantics, transfer/models.py:904-906).
+// Requires C::BN / C::WN == 64: a wave's four n-tiles are the four gates of the same 16 units.
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int* __restrict__ lens,
+                                                   const bf16raw* __restrict__ whh, float* __restrict__ G,
+                                                   float* __restrict__ Cs, bf16raw* __restrict__ Hs) {
+    static_assert(C::BN / C::WN == 64 && C::TN == 4, "one 64-column gate block per wave");
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    const int dir = blockIdx.z;
+    const int t = dir ? s.T - 1 - step : step;
+    const int tp = dir ? t + 1 : t - 1;              // time index of the previous recurrence step
+    const bool tp_ok = tp >= 0 && tp < s.T;
+    const int n0 = blockIdx.x * C::BN, b0 = blockIdx.y * C::BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        int any = 0;
+        for (int r = tid; r < C::BM; r += C::NT) {
+            const int b = b0 + r;
+            if (b < s.B && lens[b] > t) any = 1;
+        }
+        if (!__syncthreads_or(any)) return;
+    }
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    const int Hp = s.Hp, Gp = s.Gp, B = s.B;
+    if (tp_ok) {
+        const bf16raw* arow[C::ACH];
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) {
+            const int b = b0 + tid / C::CH + i * C::RSTEP;
+            arow[i] = (b < B && lens[b] > tp) ? Hs + (((long long)tp * B + b) * 2 + dir) * Hp : nullptr;
+        }
+        const bf16raw* w = whh + (long long)dir * Gp * Hp;
+        gemm_core<C, u32x4>(
+            Hp,
+            [&](int i, int, int k) {
+                return (arow[i] != nullptr && k < Hp) ? *(const u32x4*)(arow[i] + k) : u32x4{0u, 0u, 0u, 0u};
+            },
+            Ident(), [&](int, int r, int k) { return load_packed(w, Hp, n0 + r, Gp, k, Hp); }, acc, As, Bs);
+    }
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int col0 = n0 + wn * 64;                   // first permuted column of this wave's unit block
+    if (col0 >= Gp) return;
+    const int u4 = (lane >> 4) * 4;
+    const int j = (col0 >> 6) * 16 + u4;             // first of this lane's 4 hidden units
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int b = b0 + frag_row<C>(wm, tm, lane);
+        if (b >= B || lens[b] <= t) continue;
+        const long long row = ((long long)t * B + b) * 2 + dir;
+        float* g = G + row * Gp + col0 + u4;
+        const f32x4 pi = acc[tm][0] + *(const f32x4*)(g + 0);
+        const f32x4 pf = acc[tm][1] + *(const f32x4*)(g + 16);
+        const f32x4 pg = acc[tm][2] + *(const f32x4*)(g + 32);
+        const f32x4 po = acc[tm][3] + *(const f32x4*)(g + 48);
+        f32x4 cp = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tp_ok && lens[b] > tp) cp = *(const f32x4*)&Cs[(((long long)tp * B + b) * 2 + dir) * Hp + j];
+        f32x4 gi, gf, gg, go, c, h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gi[e] = sigmoidf_(pi[e]);
+            gf[e] = sigmoidf_(pf[e]);
+            gg[e] = tanhf_(pg[e]);
+            go[e] = sigmoidf_(po[e]);
+            c[e] = gf[e] * cp[e] + gi[e] * gg[e];
+            h[e] = go[e] * tanhf_(c[e]);
+        }
+        *(f32x4*)(g + 0) = gi;
+        *(f32x4*)(g + 16) = gf;
+        *(f32x4*)(g + 32) = gg;
+        *(f32x4*)(g + 48) = go;
+        *(f32x4*)&Cs[row * Hp + j] = c;
+        *(u32x2*)&Hs[row * Hp + j] = pack_bf16x4(h);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small dense layers around the recurrence (K4 and its backward):
+//   out[m][n] = sum_k A[m][k] * Bt[n][k] + bias[n]
+// AKIND 0: A is fp32 [Mrows][lda].  AKIND 1: A is the [h_fwd(len-1) | h_rev(0)] gather out of Hs
+// (hidden.view(-1,2,B,H)[-1].transpose(0,1).reshape(-1,2H), transfer/models.py:929-934).
+// ------------------------------------------------------------------------------------------------
+template <class C, int AKIND>
+__global__ __launch_bounds__(C::NT) void k_linear(Shape s, int Mrows, int N, int K, const void* __restrict__ A, int lda,
+                                                 const int* __restrict__ lens, const bf16raw* __restrict__ Bt,
+                                                 const float* __restrict__ bias, float* __restrict__ out, int ldc) {
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    const int n0 = blockIdx.x * C::BN, m0 = blockIdx.y * C::BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    if constexpr (AKIND == 0) {
+        const float* Af = (const float*)A;
+        gemm_core<C, RawF32x8>(
+            K,
+            [&](int, int r, int k) {
+                RawF32x8 v;
+                v.lo = v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int m = m0 + r;
+                if (m < Mrows && k < K) {
+                    const float* p = Af + (long long)m * lda + k;
+                    v.lo = *(const f32x4*)p;
+                    v.hi = *(const f32x4*)(p + 4);
+                }
+                return v;
+            },
+            CvtF32x8(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
+    } else {
+        const bf16raw* Hs = (const bf16raw*)A;
+        const int Hp = s.Hp, B = s.B;
+        gemm_core<C, u32x4>(
+            K,
+            [&](int, int r, int k) {
+                const int b = m0 + r;
+                if (b >= Mrows || k >= K) return u32x4{0u, 0u, 0u, 0u};
+                const int d = k >= Hp ? 1 : 0, kk = k - d * Hp;
+                const int len = lens[b];
+                if (len <= 0) return u32x4{0u, 0u, 0u, 0u};
+                const int ts = d ? 0 : len - 1;
+                return *(const u32x4*)(Hs + (((long long)ts * B + b) * 2 + d) * Hp + kk);
+            },
+            Ident(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
+    }
+    const int wm = wave / C::WN, wn = wave % C::WN;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = n0 + frag_col<C>(wn, tn, lane);
+            if (m < Mrows && n < N) {
+                f32x4 v = acc[tm][tn];
+                if (bias != nullptr) v += *(const f32x4*)&bias[n];
+                *(f32x4*)&out[(long long)m * ldc + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  fused additive attention + masked softmax + pooling + 2-way head + per-sentence CE
+// (transfer/models.py:855-880, :949; nn.CrossEntropyLoss(reduction='none'), :990,:1212).
+// One 256-thread workgroup per sentence; wave w owns time steps t = w, w+4, ...; lanes split H;
+// wavefront reductions over H, online softmax over T, cross-wave combine through LDS.
+// NV = float4 groups per lane (Hp <= NV*256).
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_MAX_T = 1024;
+constexpr int ATT_MAX_L = 64;
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_attn_fwd(Shape s, const float* __restrict__ Kk, const float* __restrict__ U,
+                                                 const unsigned char* __restrict__ need, const float* __restrict__ wa,
+                                                 const float* __restrict__ ba, const float* __restrict__ wo,
+                                                 const float* __restrict__ bo, const long long* __restrict__ labels,
+                                                 float* __restrict__ weights, float* __restrict__ ctx_out,
+                                                 float* __restrict__ logits, float* __restrict__ loss) {
+    __shared__ float sc[ATT_MAX_T];
+    __shared__ float wm_[4], wl_[4];
+    __shared__ __attribute__((aligned(16))) float cx[4][NV * 256];
+    __shared__ float lg[ATT_MAX_L];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Hp = s.Hp, B = s.B, T = s.T;
+    f32x4 u[NV], w[NV], cacc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int h = v * 256 + lane * 4;
+        u[v] = w[v] = cacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (h < Hp) {
+            u[v] = *(const f32x4*)&U[(long long)b * Hp + h];
+            w[v] = *(const f32x4*)&wa[h];
+        }
+    }
+    const float bias_a = ba[0];
+    float mx = -INFINITY, l = 0.f;
+    for (int t = wave; t < T; t += 4) {
+        const long long m = (long long)t * B + b;
+        if (!(need[m] & 2)) continue;               // masked position: weight is exactly 0
+        f32x4 kk[NV];
+        float part = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int h = v * 256 + lane * 4;
+            kk[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (h < Hp) {
+                kk[v] = *(const f32x4*)&Kk[m * Hp + h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += w[v][e] * tanhf_(kk[v][e] + u[v][e]);
+            }
+        }
+        const float sc_t = wave_sum(part) + bias_a;
+        if (lane == 0) sc[t] = sc_t;
+        const float mn = fmaxf(mx, sc_t);
+        const float scale = __expf(mx - mn), p = __expf(sc_t - mn);   // exp(-inf) = 0 on the first hit
+        l = l * scale + p;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cacc[v] = cacc[v] * scale + kk[v] * p;
+        mx = mn;
+    }
+    if (lane == 0) {
+        wm_[wave] = mx;
+        wl_[wave] = l;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *(f32x4*)&cx[wave][v * 256 + lane * 4] = cacc[v];
+    __syncthreads();
+    float gm = fmaxf(fmaxf(wm_[0], wm_[1]), fmaxf(wm_[2], wm_[3]));
+    float gl = 0.f, sw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sw[k] = (wm_[k] == -INFINITY) ? 0.f : __expf(wm_[k] - gm);
+        gl += wl_[k] * sw[k];
+    }
+    // gl == 0: every position masked -> softmax of all -inf is NaN in the reference; mirror it.
+    const float inv = gl > 0.f ? 1.0f / gl : __builtin_nanf("");
+    for (int t = tid; t < T; t += 256) {
+        const long long m = (long long)t * B + b;
+        float a = (need[m] & 2) ? __expf(sc[t] - gm) * inv : 0.f;
+        if (!(gl > 0.f)) a = inv;
+        weights[(long long)b * T + t] = a;
+    }
+    __syncthreads();   // cx[0] is rewritten below
+    for (int h = tid; h < Hp; h += 256) {
+        const float c = (cx[0][h] * sw[0] + cx[1][h] * sw[1] + cx[2][h] * sw[2] + cx[3][h] * sw[3]) * inv;
+        ctx_out[(long long)b * Hp + h] = c;
+        cx[0][h] = c;
+    }
+    __syncthreads();
+    for (int c = wave; c < s.L; c += 4) {
+        float part = 0.f;
+        for (int h = lane; h < Hp; h += 64) part += wo[(long long)c * Hp + h] * cx[0][h];
+        const float v = wave_sum(part) + bo[c];
+        if (lane == 0) {
+            logits[(long long)b * s.L + c] = v;
+            lg[c] = v;
+        }
+    }
+    if (loss != nullptr && labels != nullptr) {
+        __syncthreads();
+        if (tid == 0) {
+            float m2 = -INFINITY;
+            for (int c = 0; c < s.L; ++c) m2 = fmaxf(m2, lg[c]);
+            float se = 0.f;
+            for (int c = 0; c < s.L; ++c) se += __expf(lg[c] - m2);
+            const long long lab = labels[b];
+            loss[b] = (lab >= 0 && lab < s.L) ? (__logf(se) + m2 - lg[lab]) : __builtin_nanf("");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5'  backward of K5: dlogits (given, or CE(logits,labels)*dloss) -> dKk (bf16, written into the
+// key columns of DZ for EVERY t, zeros where masked) and du = d linear_q(q).
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restrict__ Kk, const float* __restrict__ U,
+                                                 const float* __restrict__ wa, const float* __restrict__ wo,
+                                                 const float* __restrict__ weights, const float* __restrict__ ctx,
+                                                 const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                 const float* __restrict__ dlogits, const float* __restrict__ dloss,
+                                                 float dloss_scale, const float* __restrict__ dweights,
+                                                 bf16raw* __restrict__ DZ, float* __restrict__ DU) {
+    __shared__ float dl[ATT_MAX_L];
+    __shared__ __attribute__((aligned(16))) float dux[4][NV * 256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Hp = s.Hp, B = s.B, T = s.T, L = s.L;
+    if (tid == 0) {
+        if (dlogits != nullptr) {
+            for (int c = 0; c < L; ++c) dl[c] = dlogits[(long long)b * L + c];
+        } else {
+            const float up = dloss != nullptr ? dloss[b] : dloss_scale;
+            float m2 = -INFINITY;
+            for (int c = 0; c < L; ++c) m2 = fmaxf(m2, logits[(long long)b * L + c]);
+            float se = 0.f;
+            for (int c = 0; c < L; ++c) se += __expf(logits[(long long)b * L + c] - m2);
+            const long long lab = labels[b];
+            for (int c = 0; c < L; ++c)
+                dl[c] = (__expf(logits[(long long)b * L + c] - m2) / se - (c == lab ? 1.f : 0.f)) * up;
+        }
+    }
+    __syncthreads();
+    f32x4 u[NV], w[NV], dctx[NV], du[NV];
+    float dpart = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int h = v * 256 + lane * 4;
+        u[v] = w[v] = dctx[v] = du[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (h < Hp) {
+            u[v] = *(const f32x4*)&U[(long long)b * Hp + h];
+            w[v] = *(const f32x4*)&wa[h];
+            for (int c = 0; c < L; ++c) dctx[v] += *(const f32x4*)&wo[(long long)c * Hp + h] * dl[c];
+            const f32x4 cv = *(const f32x4*)&ctx[(long long)b * Hp + h];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dpart += dctx[v][e] * cv[e];
+        }
+    }
+    // delta = sum_t a_t * da_t = dctx . ctx (+ sum_t a_t * dweights_t); every wave computes it.
+    if (dweights != nullptr)
+        for (int t = lane; t < T; t += 64) {
+            const float a = weights[(long long)b * T + t];
+            if (a > 0.f) dpart += a * dweights[(long long)b * T + t];
+        }
+    const float delta = wave_sum(dpart);
+    for (int t = wave; t < T; t += 4) {
+        const long long m = (long long)t * B + b;
+        bf16raw* dz = DZ + m * s.Ncat + 2 * s.Gp;
+        const float a = weights[(long long)b * T + t];
+        if (!(a > 0.f)) {   // masked (exact 0), underflowed, or NaN row
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int h = v * 256 + lane * 4;
+                if (h < Hp) *(u32x2*)&dz[h] = u32x2{0u, 0u};
+            }
+            continue;
+        }
+        f32x4 kk[NV], om[NV];
+        float part = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int h = v * 256 + lane * 4;
+            kk[v] = om[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (h < Hp) {
+                kk[v] = *(const f32x4*)&Kk[m * Hp + h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mid = tanhf_(kk[v][e] + u[v][e]);
+                    om[v][e] = 1.f - mid * mid;
+                    part += dctx[v][e] * kk[v][e];
+                }
+            }
+        }
+        float da = wave_sum(part);
+        if (dweights != nullptr) da += dweights[(long long)b * T + t];
+        const float ds = a * (da - delta);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int h = v * 256 + lane * 4;
+            if (h < Hp) {
+                const f32x4 dpre = om[v] * w[v] * ds;
+                du[v] += dpre;
+                *(u32x2*)&dz[h] = pack_bf16x4(dctx[v] * a + dpre);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *(f32x4*)&dux[wave][v * 256 + lane * 4] = du[v];
+    __syncthreads();
+    for (int h = tid; h < Hp; h += 256) DU[(long long)b * Hp + h] = dux[0][h] + dux[1][h] + dux[2][h] + dux[3][h];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2'  one BPTT step of the LSTM (both directions), frozen weights:
+//   dh_t = dZ_{next} . W_hh  (+ d h_final at the row's last forward step), gate derivatives,
+//   dZ_t -> DZ (bf16, zeros for t >= len[b]); dc carried in DC.
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int* __restrict__ lens,
+                                                   const bf16raw* __restrict__ whhT, const float* __restrict__ G,
+                                                   const float* __restrict__ Cs, const float* __restrict__ DHFIN,
+                                                   float* __restrict__ DC, bf16raw* __restrict__ DZ) {
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    const int dir = blockIdx.z;
+    const int t = dir ? step : s.T - 1 - step;       // reverse of the forward order
+    const int tn = dir ? t - 1 : t + 1;              // step whose dZ feeds dh_t (processed one launch ago)
+    const int tpf = dir ? t + 1 : t - 1;             // forward-previous step (source of c_prev)
+    const bool tn_ok = tn >= 0 && tn < s.T, tpf_ok = tpf >= 0 && tpf < s.T;
+    const int n0 = blockIdx.x * C::BN, b0 = blockIdx.y * C::BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Hp = s.Hp, Gp = s.Gp, B = s.B, Ncat = s.Ncat;
+    int any = 0;
+    for (int r = tid; r < C::BM; r += C::NT) {
+        const int b = b0 + r;
+        if (b < B && lens[b] > t) any = 1;
+    }
+    any = __syncthreads_or(any);
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    if (any && tn_ok) {
+        const bf16raw* arow[C::ACH];
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) {
+            const int b = b0 + tid / C::CH + i * C::RSTEP;
+            arow[i] = (b < B && lens[b] > tn && lens[b] > t) ? DZ + ((long long)tn * B + b) * Ncat + (long long)dir * Gp : nullptr;
+        }
+        const bf16raw* w = whhT + (long long)dir * Hp * Gp;
+        gemm_core<C, u32x4>(
+            Gp,
+            [&](int i, int, int k) {
+                return (arow[i] != nullptr && k < Gp) ? *(const u32x4*)(arow[i] + k) : u32x4{0u, 0u, 0u, 0u};
+            },
+            Ident(), [&](int, int r, int k) { return load_packed(w, Gp, n0 + r, Hp, k, Gp); }, acc, As, Bs);
+    }
+    const int wm = wave / C::WN, wn = wave % C::WN;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int b = b0 + frag_row<C>(wm, tm, lane);
+        if (b >= B) continue;
+        const int len = lens[b];
+        const bool act = len > t;
+        const bool last = dir ? (t == 0) : (t == len - 1);
+        const long long row = ((long long)t * B + b) * 2 + dir;
+        bf16raw* zrow = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+#pragma unroll
+        for (int tnn = 0; tnn < C::TN; ++tnn) {
+            const int j = n0 + frag_col<C>(wn, tnn, lane);   // 4 consecutive hidden units
+            if (j >= Hp) continue;
+            const int pc = (j >> 4) * 64 + (j & 15);         // permuted column of gate 0
+            if (!act) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(u32x2*)&zrow[pc + g * 16] = u32x2{0u, 0u};
+                continue;
+            }
+            f32x4 dh = acc[tm][tnn];
+            if (last) dh += *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + j];
+            f32x4 dc = f32x4{0.f, 0.f, 0.f, 0.f}, cp = f32x4{0.f, 0.f, 0.f, 0.f};
+            float* dcp = DC + (long long)b * 2 * Hp + dir * Hp + j;
+            if (tn_ok && len > tn) dc = *(const f32x4*)dcp;
+            if (tpf_ok && len > tpf) cp = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + j];
+            const float* g = G + row * Gp + pc;
+            const f32x4 gi = *(const f32x4*)(g + 0), gf = *(const f32x4*)(g + 16);
+            const f32x4 gg = *(const f32x4*)(g + 32), go = *(const f32x4*)(g + 48);
+            const f32x4 c = *(const f32x4*)&Cs[row * Hp + j];
+            f32x4 zi, zf, zg, zo, dcn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tc = tanhf_(c[e]);
+                const float d_o = dh[e] * tc;
+                const float dct = dc[e] + dh[e] * go[e] * (1.f - tc * tc);
+                zi[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+                zf[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+                zg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+                zo[e] = d_o * go[e] * (1.f - go[e]);
+                dcn[e] = dct * gf[e];
+            }
+            *(u32x2*)&zrow[pc + 0] = pack_bf16x4(zi);
+            *(u32x2*)&zrow[pc + 16] = pack_bf16x4(zf);
+            *(u32x2*)&zrow[pc + 32] = pack_bf16x4(zg);
+            *(u32x2*)&zrow[pc + 48] = pack_bf16x4(zo);
+            *(f32x4*)dcp = dcn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a' + K3'  dX[m] = DZ[m] . Wcat   (dgrad of both LSTM input projections and of linear_emb)
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(C::NT) void k_inproj_bwd(Shape s, const bf16raw* __restrict__ DZ,
+                                                     const unsigned char* __restrict__ need,
+                                                     const bf16raw* __restrict__ wcatT, bf16raw* __restrict__ DX) {
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    const int m0 = blockIdx.x * C::BM, n0 = blockIdx.y * C::BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    const int Ep = s.Ep, M = s.M, Ncat = s.Ncat;
+    if (tile_any_need<C>(need, m0, M)) {
+        gemm_core<C, u32x4>(
+            Ncat, [&](int, int r, int k) { return load_packed(DZ, Ncat, m0 + r, M, k, Ncat); }, Ident(),
+            [&](int, int r, int k) { return load_packed(wcatT, Ncat, n0 + r, Ep, k, Ncat); }, acc, As, Bs);
+    }
+    const int wm = wave / C::WN, wn = wave % C::WN;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = n0 + frag_col<C>(wn, tn, lane);
+            if (m < M && n < Ep) *(u32x2*)&DX[(long long)m * Ep + n] = pack_bf16x4(acc[tm][tn]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1'  d(soft tokens)  dS[m][v] = sum_e dX[m][e] * W_emb[v][e]   (autograd of transfer/models.py:898)
+// Every (m, v) is written (exact zeros for t >= len[b]), in the caller's dtype and strides.
+// ------------------------------------------------------------------------------------------------
+template <class C, int KIND>
+__global__ __launch_bounds__(C::NT) void k_softemb_bwd(Shape s, const bf16raw* __restrict__ DX,
+                                                      const unsigned char* __restrict__ need,
+                                                      const bf16raw* __restrict__ wemb, void* __restrict__ dS,
+                                                      long long sT, long long sB) {
+    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
+    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
+    const int n0 = blockIdx.x * C::BN, m0 = blockIdx.y * C::BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    const int Ep = s.Ep, M = s.M, V = s.V, Vp = s.Vp;
+    if (tile_any_need<C>(need, m0, M)) {
+        gemm_core<C, u32x4>(
+            Ep, [&](int, int r, int k) { return load_packed(DX, Ep, m0 + r, M, k, Ep); }, Ident(),
+            [&](int, int r, int k) { return load_packed(wemb, Ep, n0 + r, Vp, k, Ep); }, acc, As, Bs);
+    }
+    const int wm = wave / C::WN, wn = wave % C::WN;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+        if (m >= M) continue;
+        const int t = m / s.B, b = m - t * s.B;
+        const long long base = (long long)t * sT + (long long)b * sB;
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = n0 + frag_col<C>(wn, tn, lane);
+            if (n >= V) continue;
+            const f32x4 v = acc[tm][tn];
+            if constexpr (KIND == SRC_F32) {
+                float* p = (float*)dS + base + n;
+                if (n + 4 <= V) {
+                    *(f32x4u*)p = v;
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < V) p[e] = v[e];
+                }
+            } else {
+                bf16raw* p = (bf16raw*)dS + base + n;
+                if (n + 4 <= V) {
+                    *(u32x2h*)p = pack_bf16x4(v);
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < V) p[e] = f32_to_bf16(v[e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: fp32 state_dict tensors -> padded / permuted / transposed bf16 (or fp32) images.
+// dst[r][c] = src[sr][sc] with (sr, sc) = TR ? (cmap(c), rmap(r)) : (rmap(r), cmap(c)); -1 -> 0.
+// ------------------------------------------------------------------------------------------------
+enum { MAP_ID = 0, MAP_GATE = 1, MAP_HCAT = 2 };
+struct IdxMap {
+    int kind, limit, H, Hp;
+};
+__device__ __forceinline__ int map_idx(const IdxMap& m, int i) {
+    if (m.kind == MAP_ID) return i < m.limit ? i : -1;
+    if (m.kind == MAP_GATE) {
+        const int ub = i >> 6, g = (i & 63) >> 4, u = i & 15, unit = ub * 16 + u;
+        return unit < m.H ? g * m.H + unit : -1;
+    }
+    const int d = i / m.Hp, j = i - d * m.Hp;
+    return j < m.H ? d * m.H + j : -1;
+}
+template <typename OutT>
+__global__ void k_pack(OutT* __restrict__ dst, int rows, int cols, long long ldd, const float* __restrict__ src,
+                       const float* __restrict__ src2, long long lds, IdxMap rmap, IdxMap cmap, int tr) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        const int a = map_idx(rmap, r), bb = map_idx(cmap, c);
+        float v = 0.f;
+        if (a >= 0 && bb >= 0) {
+            const long long si = tr ? (long long)bb * lds + a : (long long)a * lds + bb;
+            v = src[si];
+            if (src2 != nullptr) v += src2[si];
+        }
+        if constexpr (sizeof(OutT) == 2)
+            dst[(long long)r * ldd + c] = f32_to_bf16(v);
+        else
+            dst[(long long)r * ldd + c] = v;
+    }
+}
+
+}  // namespace sad

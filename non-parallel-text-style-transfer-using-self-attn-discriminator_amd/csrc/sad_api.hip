@@ -1,0 +1,492 @@
+// libsad host side: C-ABI entry points (include/sad.h), layouts, argument checks, launches.
+// gfx950 only.  Nothing here allocates, frees or synchronises.
+#include "../../include/sad.h"
+#include "kernels.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+using namespace sad;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SAD_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) return fail(-2, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct PackedLayout {
+    size_t wembT, wemb, wcat, wcatT, bcat, whh, whhT, whb0, whb0T, bhb0, wq, wqT, bq, wa, ba, wo, bo, total;
+};
+PackedLayout packed_layout(const Shape& s) {
+    PackedLayout p;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o = align_up(o + bytes);
+        return r;
+    };
+    p.wembT = take((size_t)s.Ep * s.Vp * 2);
+    p.wemb = take((size_t)s.Vp * s.Ep * 2);
+    p.wcat = take((size_t)s.Ncat * s.Ep * 2);
+    p.wcatT = take((size_t)s.Ep * s.Ncat * 2);
+    p.bcat = take((size_t)s.Ncat * 4);
+    p.whh = take((size_t)2 * s.Gp * s.Hp * 2);
+    p.whhT = take((size_t)2 * s.Hp * s.Gp * 2);
+    p.whb0 = take((size_t)s.Hp * 2 * s.Hp * 2);
+    p.whb0T = take((size_t)2 * s.Hp * s.Hp * 2);
+    p.bhb0 = take((size_t)s.Hp * 4);
+    p.wq = take((size_t)s.Hp * s.Hp * 2);
+    p.wqT = take((size_t)s.Hp * s.Hp * 2);
+    p.bq = take((size_t)s.Hp * 4);
+    p.wa = take((size_t)s.Hp * 4);
+    p.ba = take(4);
+    p.wo = take((size_t)s.L * s.Hp * 4);
+    p.bo = take((size_t)s.L * 4);
+    p.total = o;
+    return p;
+}
+
+struct WsLayout {
+    size_t off[SAD_WS_NFIELDS], bytes[SAD_WS_NFIELDS], total;
+};
+WsLayout ws_layout(const Shape& s) {
+    WsLayout w;
+    const size_t M = (size_t)s.M, B = (size_t)s.B;
+    w.bytes[SAD_WS_LENS] = B * 4;
+    w.bytes[SAD_WS_NEED] = M;
+    w.bytes[SAD_WS_X] = M * s.Ep * 2;
+    w.bytes[SAD_WS_G] = M * 2 * s.Gp * 4;
+    w.bytes[SAD_WS_CS] = M * 2 * s.Hp * 4;
+    w.bytes[SAD_WS_HS] = M * 2 * s.Hp * 2;
+    w.bytes[SAD_WS_KK] = M * s.Hp * 4;
+    w.bytes[SAD_WS_Q] = B * s.Hp * 4;
+    w.bytes[SAD_WS_U] = B * s.Hp * 4;
+    w.bytes[SAD_WS_CTX] = B * s.Hp * 4;
+    w.bytes[SAD_WS_DZ] = M * s.Ncat * 2;
+    w.bytes[SAD_WS_DX] = M * s.Ep * 2;
+    w.bytes[SAD_WS_DU] = B * s.Hp * 4;
+    w.bytes[SAD_WS_DQ] = B * s.Hp * 4;
+    w.bytes[SAD_WS_DHFIN] = B * 2 * s.Hp * 4;
+    w.bytes[SAD_WS_DC] = B * 2 * s.Hp * 4;
+    size_t o = 0;
+    for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
+        w.off[i] = o;
+        o = align_up(o + w.bytes[i]);
+    }
+    w.total = o;
+    return w;
+}
+
+int check_dims(const sad_dims* d, Shape* s) {
+    if (d == nullptr) return fail(-1, "dims is NULL");
+    if (d->B < 1 || d->T < 1 || d->V < 1 || d->E < 1 || d->H < 1 || d->L < 1)
+        return fail(-1, "dims must be positive (B=%d T=%d V=%d E=%d H=%d L=%d)", d->B, d->T, d->V, d->E, d->H, d->L);
+    if (d->T > ATT_MAX_T) return fail(-1, "T=%d exceeds the supported maximum %d", d->T, ATT_MAX_T);
+    if (d->L > ATT_MAX_L) return fail(-1, "L=%d exceeds the supported maximum %d", d->L, ATT_MAX_L);
+    if (d->H > 2048) return fail(-1, "H=%d exceeds the supported maximum 2048", d->H);
+    if ((long long)d->B * d->T > (1ll << 30)) return fail(-1, "B*T too large");
+    if (d->B > 65535 * 64) return fail(-1, "B too large");
+    *s = make_shape(d->B, d->T, d->V, d->E, d->H, d->L);
+    return 0;
+}
+
+template <class T>
+T* at(void* base, size_t off) { return (T*)((char*)base + off); }
+template <class T>
+const T* at(const void* base, size_t off) { return (const T*)((const char*)base + off); }
+
+int check_ptr(const void* p, const char* name) {
+    if (p == nullptr) return fail(-1, "%s is NULL", name);
+    return 0;
+}
+int check_aligned(const void* p, size_t a, const char* name) {
+    if (((uintptr_t)p) % a) return fail(-1, "%s must be %zu-byte aligned", name, a);
+    return 0;
+}
+
+typedef Cfg<128, 320, 2, 4> CfgWideN;   // 512 threads; all of Ep=320 in one tile: S is read once
+typedef Cfg<128, 64, 2, 2> CfgNarrowN;
+typedef Cfg<128, 128, 2, 2> CfgSquare;
+typedef Cfg<64, 64, 2, 2> CfgSmall;
+typedef Cfg<64, 64, 4, 1> CfgStepSmall; // LSTM step, small batch: 16 rows x one 64-col gate block per wave
+
+template <class C, int KIND>
+void launch_softemb_fwd(const Shape& s, const void* src, long long sT, long long sB, const unsigned char* need,
+                        const bf16raw* wembT, bf16raw* X, hipStream_t st) {
+    dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN));
+    hipLaunchKernelGGL((k_softemb_fwd<C, KIND>), grid, dim3(C::NT), 0, st, s, src, sT, sB, need, wembT, X);
+}
+template <class C, int KIND>
+void launch_softemb_bwd(const Shape& s, const bf16raw* DX, const unsigned char* need, const bf16raw* wemb, void* dS,
+                        long long sT, long long sB, hipStream_t st) {
+    dim3 grid(ceil_div(s.V, C::BN), ceil_div(s.M, C::BM));
+    hipLaunchKernelGGL((k_softemb_bwd<C, KIND>), grid, dim3(C::NT), 0, st, s, DX, need, wemb, dS, sT, sB);
+}
+
+int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, const void* packed, void* ws,
+                    const void* src, int kind, long long sB, long long sT, hipStream_t st) {
+    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
+    const bf16raw* wembT = at<bf16raw>(packed, pl.wembT);
+    bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
+    const bool wide = s.Ep > 128;
+    if (kind == SAD_SRC_F32) {
+        if (check_aligned(src, 4, "src")) return -1;
+        if (wide) launch_softemb_fwd<CfgWideN, SRC_F32>(s, src, sT, sB, need, wembT, X, st);
+        else launch_softemb_fwd<CfgNarrowN, SRC_F32>(s, src, sT, sB, need, wembT, X, st);
+    } else if (kind == SAD_SRC_BF16) {
+        if (check_aligned(src, 2, "src")) return -1;
+        if (wide) launch_softemb_fwd<CfgWideN, SRC_BF16>(s, src, sT, sB, need, wembT, X, st);
+        else launch_softemb_fwd<CfgNarrowN, SRC_BF16>(s, src, sT, sB, need, wembT, X, st);
+    } else {
+        return fail(-1, "soft-embedding stage needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
+    }
+    SAD_CHECK_LAUNCH("k_softemb_fwd");
+    return 0;
+}
+
+int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, const void* packed, void* ws,
+                    void* dsrc, int kind, long long sB, long long sT, hipStream_t st) {
+    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
+    const bf16raw* wemb = at<bf16raw>(packed, pl.wemb);
+    const bf16raw* DX = at<bf16raw>(ws, wl.off[SAD_WS_DX]);
+    if (kind == SAD_SRC_F32) {
+        if (check_aligned(dsrc, 4, "dsrc")) return -1;
+        launch_softemb_bwd<CfgSquare, SRC_F32>(s, DX, need, wemb, dsrc, sT, sB, st);
+    } else if (kind == SAD_SRC_BF16) {
+        if (check_aligned(dsrc, 2, "dsrc")) return -1;
+        launch_softemb_bwd<CfgSquare, SRC_BF16>(s, DX, need, wemb, dsrc, sT, sB, st);
+    } else {
+        return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
+    }
+    SAD_CHECK_LAUNCH("k_softemb_bwd");
+    return 0;
+}
+
+int run_prep(const Shape& s, const WsLayout& wl, void* ws, const int32_t* lengths, uint8_t* mask, long long msb,
+             long long mst, int guard, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep, dim3(ceil_div(s.B, 64)), dim3(64), 0, st, s, lengths, mask, msb, mst, guard,
+                       at<unsigned char>(ws, wl.off[SAD_WS_NEED]), at<int>(ws, wl.off[SAD_WS_LENS]));
+    SAD_CHECK_LAUNCH("k_prep");
+    return 0;
+}
+
+template <typename OutT>
+void launch_pack(OutT* dst, int rows, int cols, long long ldd, const float* src, const float* src2, long long lds,
+                 IdxMap rmap, IdxMap cmap, int tr, hipStream_t st) {
+    const long long total = (long long)rows * cols;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_pack<OutT>), dim3(blocks), dim3(256), 0, st, dst, rows, cols, ldd, src, src2, lds, rmap, cmap, tr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sad_version(void) { return SAD_VERSION; }
+const char* sad_last_error(void) { return g_err; }
+
+int sad_padded_dims(const sad_dims* d, int32_t out[5]) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    out[0] = s.Ep; out[1] = s.Hp; out[2] = s.Gp; out[3] = s.Vp; out[4] = s.Ncat;
+    return 0;
+}
+
+size_t sad_packed_bytes(const sad_dims* d) {
+    Shape s;
+    if (check_dims(d, &s)) return 0;
+    return packed_layout(s).total;
+}
+
+size_t sad_workspace_bytes(const sad_dims* d) {
+    Shape s;
+    if (check_dims(d, &s)) return 0;
+    return ws_layout(s).total;
+}
+
+int sad_workspace_field(const sad_dims* d, int field, size_t* offset, size_t* bytes) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (field < 0 || field >= SAD_WS_NFIELDS) return fail(-1, "unknown workspace field %d", field);
+    WsLayout w = ws_layout(s);
+    if (offset) *offset = w.off[field];
+    if (bytes) *bytes = w.bytes[field];
+    return 0;
+}
+
+int sad_pack_weights(const sad_dims* d, const sad_weights* w, void* packed, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(w, "weights") || check_ptr(packed, "packed") || check_aligned(packed, 256, "packed")) return -1;
+    const void* need[] = {w->embedding_weight, w->rnn_weight_ih[0], w->rnn_weight_ih[1], w->rnn_weight_hh[0],
+                          w->rnn_weight_hh[1], w->rnn_bias_ih[0], w->rnn_bias_ih[1], w->rnn_bias_hh[0],
+                          w->rnn_bias_hh[1], w->hidden_bridge0_weight, w->hidden_bridge0_bias, w->linear_emb_weight,
+                          w->linear_emb_bias, w->linear_q_weight, w->linear_q_bias, w->linear_attn_weight,
+                          w->linear_attn_bias, w->output_layer_weight, w->output_layer_bias};
+    for (size_t i = 0; i < sizeof(need) / sizeof(need[0]); ++i)
+        if (need[i] == nullptr) return fail(-1, "sad_weights field #%zu is NULL", i);
+    hipStream_t st = (hipStream_t)stream;
+    const PackedLayout p = packed_layout(s);
+    const IdxMap idE{MAP_ID, s.E, s.H, s.Hp}, idV{MAP_ID, s.V, s.H, s.Hp}, idH{MAP_ID, s.H, s.H, s.Hp};
+    const IdxMap idL{MAP_ID, s.L, s.H, s.Hp}, id1{MAP_ID, 1, s.H, s.Hp};
+    const IdxMap gate{MAP_GATE, 0, s.H, s.Hp}, hcat{MAP_HCAT, 0, s.H, s.Hp};
+    // embedding: [Ep][Vp] (K1's Bt) and [Vp][Ep] (K1' Bt, and the hard-token gather table)
+    launch_pack(at<bf16raw>(packed, p.wembT), s.Ep, s.Vp, s.Vp, w->embedding_weight, nullptr, s.E, idE, idV, 1, st);
+    launch_pack(at<bf16raw>(packed, p.wemb), s.Vp, s.Ep, s.Ep, w->embedding_weight, nullptr, s.E, idV, idE, 0, st);
+    // fused in-projection [Ncat][Ep], its transpose [Ep][Ncat], bias [Ncat]
+    for (int dir = 0; dir < 2; ++dir) {
+        launch_pack(at<bf16raw>(packed, p.wcat) + (size_t)dir * s.Gp * s.Ep, s.Gp, s.Ep, s.Ep, w->rnn_weight_ih[dir],
+                    nullptr, s.E, gate, idE, 0, st);
+        launch_pack(at<bf16raw>(packed, p.wcatT) + (size_t)dir * s.Gp, s.Ep, s.Gp, s.Ncat, w->rnn_weight_ih[dir],
+                    nullptr, s.E, idE, gate, 1, st);
+        launch_pack(at<float>(packed, p.bcat) + (size_t)dir * s.Gp, 1, s.Gp, s.Gp, w->rnn_bias_ih[dir],
+                    w->rnn_bias_hh[dir], 4 * s.H, id1, gate, 0, st);
+        launch_pack(at<bf16raw>(packed, p.whh) + (size_t)dir * s.Gp * s.Hp, s.Gp, s.Hp, s.Hp, w->rnn_weight_hh[dir],
+                    nullptr, s.H, gate, idH, 0, st);
+        launch_pack(at<bf16raw>(packed, p.whhT) + (size_t)dir * s.Hp * s.Gp, s.Hp, s.Gp, s.Gp, w->rnn_weight_hh[dir],
+                    nullptr, s.H, idH, gate, 1, st);
+    }
+    launch_pack(at<bf16raw>(packed, p.wcat) + (size_t)2 * s.Gp * s.Ep, s.Hp, s.Ep, s.Ep, w->linear_emb_weight, nullptr,
+                s.E, idH, idE, 0, st);
+    launch_pack(at<bf16raw>(packed, p.wcatT) + (size_t)2 * s.Gp, s.Ep, s.Hp, s.Ncat, w->linear_emb_weight, nullptr, s.E,
+                idE, idH, 1, st);
+    launch_pack(at<float>(packed, p.bcat) + (size_t)2 * s.Gp, 1, s.Hp, s.Hp, w->linear_emb_bias, nullptr, s.H, id1, idH,
+                0, st);
+    // hidden_bridges[0]: [Hp][2Hp] over k = [h_fwd | h_rev], and its transpose
+    launch_pack(at<bf16raw>(packed, p.whb0), s.Hp, 2 * s.Hp, 2 * s.Hp, w->hidden_bridge0_weight, nullptr, 2 * s.H, idH,
+                hcat, 0, st);
+    launch_pack(at<bf16raw>(packed, p.whb0T), 2 * s.Hp, s.Hp, s.Hp, w->hidden_bridge0_weight, nullptr, 2 * s.H, hcat,
+                idH, 1, st);
+    launch_pack(at<float>(packed, p.bhb0), 1, s.Hp, s.Hp, w->hidden_bridge0_bias, nullptr, s.H, id1, idH, 0, st);
+    launch_pack(at<bf16raw>(packed, p.wq), s.Hp, s.Hp, s.Hp, w->linear_q_weight, nullptr, s.H, idH, idH, 0, st);
+    launch_pack(at<bf16raw>(packed, p.wqT), s.Hp, s.Hp, s.Hp, w->linear_q_weight, nullptr, s.H, idH, idH, 1, st);
+    launch_pack(at<float>(packed, p.bq), 1, s.Hp, s.Hp, w->linear_q_bias, nullptr, s.H, id1, idH, 0, st);
+    launch_pack(at<float>(packed, p.wa), 1, s.Hp, s.Hp, w->linear_attn_weight, nullptr, s.H, id1, idH, 0, st);
+    launch_pack(at<float>(packed, p.ba), 1, 1, 1, w->linear_attn_bias, nullptr, 1, id1, id1, 0, st);
+    launch_pack(at<float>(packed, p.wo), s.L, s.Hp, s.Hp, w->output_layer_weight, nullptr, s.H, idL, idH, 0, st);
+    launch_pack(at<float>(packed, p.bo), 1, s.L, s.L, w->output_layer_bias, nullptr, s.L, id1, idL, 0, st);
+    SAD_CHECK_LAUNCH("k_pack");
+    return 0;
+}
+
+int sad_prep(const sad_dims* d, const int32_t* lengths, uint8_t* mask, int64_t msb, int64_t mst, int32_t guard,
+             void* workspace, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(lengths, "lengths") || check_ptr(mask, "mask") || check_ptr(workspace, "workspace") ||
+        check_aligned(workspace, 256, "workspace"))
+        return -1;
+    return run_prep(s, ws_layout(s), workspace, lengths, mask, msb, mst, guard, (hipStream_t)stream);
+}
+
+int sad_softemb_fwd(const sad_dims* d, const void* packed, const void* src, int32_t kind, int64_t sB, int64_t sT,
+                    void* workspace, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(packed, "packed") || check_ptr(src, "src") || check_ptr(workspace, "workspace") ||
+        check_aligned(workspace, 256, "workspace") || check_aligned(packed, 256, "packed"))
+        return -1;
+    return run_softemb_fwd(s, packed_layout(s), ws_layout(s), packed, workspace, src, kind, sB, sT, (hipStream_t)stream);
+}
+
+int sad_softemb_bwd(const sad_dims* d, const void* packed, void* dsrc, int32_t kind, int64_t sB, int64_t sT,
+                    void* workspace, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(packed, "packed") || check_ptr(dsrc, "dsrc") || check_ptr(workspace, "workspace") ||
+        check_aligned(workspace, 256, "workspace") || check_aligned(packed, 256, "packed"))
+        return -1;
+    return run_softemb_bwd(s, packed_layout(s), ws_layout(s), packed, workspace, dsrc, kind, sB, sT, (hipStream_t)stream);
+}
+
+int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* ws, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(a, "args") || check_ptr(packed, "packed") || check_ptr(ws, "workspace") ||
+        check_aligned(ws, 256, "workspace") || check_aligned(packed, 256, "packed"))
+        return -1;
+    if (check_ptr(a->src, "src") || check_ptr(a->lengths, "lengths") || check_ptr(a->mask, "mask") ||
+        check_ptr(a->logits, "logits") || check_ptr(a->weights, "weights"))
+        return -1;
+    if (a->loss != nullptr && a->labels == nullptr) return fail(-1, "loss requested without labels");
+    hipStream_t st = (hipStream_t)stream;
+    const PackedLayout pl = packed_layout(s);
+    const WsLayout wl = ws_layout(s);
+    const int* lens = at<int>(ws, wl.off[SAD_WS_LENS]);
+    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
+    bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
+    float* G = at<float>(ws, wl.off[SAD_WS_G]);
+    float* Cs = at<float>(ws, wl.off[SAD_WS_CS]);
+    bf16raw* Hs = at<bf16raw>(ws, wl.off[SAD_WS_HS]);
+    float* Kk = at<float>(ws, wl.off[SAD_WS_KK]);
+    float* Q = at<float>(ws, wl.off[SAD_WS_Q]);
+    float* U = at<float>(ws, wl.off[SAD_WS_U]);
+    float* CTX = at<float>(ws, wl.off[SAD_WS_CTX]);
+
+    int rc = run_prep(s, wl, ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, st);
+    if (rc) return rc;
+
+    // K1 / gather
+    if (a->src_kind == SAD_SRC_IDS) {
+        if (check_aligned(a->src, 8, "src")) return -1;
+        const long long chunks = (long long)s.M * (s.Ep / 8);
+        int blocks = (int)((chunks + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_embed_gather, dim3(blocks), dim3(256), 0, st, s, (const long long*)a->src,
+                           (long long)a->src_stride_b, (long long)a->src_stride_t, at<bf16raw>(packed, pl.wemb), X);
+        SAD_CHECK_LAUNCH("k_embed_gather");
+    } else {
+        rc = run_softemb_fwd(s, pl, wl, packed, ws, a->src, a->src_kind, a->src_stride_b, a->src_stride_t, st);
+        if (rc) return rc;
+    }
+
+    // K2a + K3
+    {
+        typedef CfgSquare C;
+        dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
+        hipLaunchKernelGGL((k_inproj_fwd<C>), grid, dim3(C::NT), 0, st, s, X, need, at<bf16raw>(packed, pl.wcat),
+                           at<float>(packed, pl.bcat), G, Kk);
+        SAD_CHECK_LAUNCH("k_inproj_fwd");
+    }
+
+    // K2b: T dependent steps, both directions per launch
+    for (int step = 0; step < s.T; ++step) {
+        if (s.B >= 512) {
+            typedef CfgSquare C;
+            dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
+            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs);
+        } else {
+            typedef CfgStepSmall C;
+            dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
+            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs);
+        }
+    }
+    SAD_CHECK_LAUNCH("k_lstm_fwd");
+
+    // K4: q = hidden_bridges[0]([h_fwd | h_rev]), u = linear_q(q)
+    {
+        typedef CfgSmall C;
+        dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
+        hipLaunchKernelGGL((k_linear<C, 1>), grid, dim3(C::NT), 0, st, s, s.B, s.Hp, 2 * s.Hp, (const void*)Hs, 0, lens,
+                           at<bf16raw>(packed, pl.whb0), at<float>(packed, pl.bhb0), Q, s.Hp);
+        hipLaunchKernelGGL((k_linear<C, 0>), grid, dim3(C::NT), 0, st, s, s.B, s.Hp, s.Hp, (const void*)Q, s.Hp, lens,
+                           at<bf16raw>(packed, pl.wq), at<float>(packed, pl.bq), U, s.Hp);
+        SAD_CHECK_LAUNCH("k_linear");
+    }
+
+    // K5
+    {
+        const float* wa = at<float>(packed, pl.wa);
+        const float* ba = at<float>(packed, pl.ba);
+        const float* wo = at<float>(packed, pl.wo);
+        const float* bo = at<float>(packed, pl.bo);
+        const long long* lab = (const long long*)a->labels;
+#define SAD_ATT_FWD(NV)                                                                                              \
+    hipLaunchKernelGGL((k_attn_fwd<NV>), dim3(s.B), dim3(256), 0, st, s, Kk, U, need, wa, ba, wo, bo, lab, a->weights, \
+                       CTX, a->logits, a->loss)
+        if (s.Hp <= 256) SAD_ATT_FWD(1);
+        else if (s.Hp <= 512) SAD_ATT_FWD(2);
+        else if (s.Hp <= 1024) SAD_ATT_FWD(4);
+        else SAD_ATT_FWD(8);
+#undef SAD_ATT_FWD
+        SAD_CHECK_LAUNCH("k_attn_fwd");
+    }
+    return 0;
+}
+
+int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* ws, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(a, "args") || check_ptr(packed, "packed") || check_ptr(ws, "workspace") ||
+        check_aligned(ws, 256, "workspace") || check_aligned(packed, 256, "packed"))
+        return -1;
+    if (check_ptr(a->weights, "weights") || check_ptr(a->logits, "logits")) return -1;
+    if (a->dlogits == nullptr && a->labels == nullptr) return fail(-1, "need dlogits, or labels (+ dloss / dloss_scale)");
+    hipStream_t st = (hipStream_t)stream;
+    const PackedLayout pl = packed_layout(s);
+    const WsLayout wl = ws_layout(s);
+    const int* lens = at<int>(ws, wl.off[SAD_WS_LENS]);
+    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
+    const float* G = at<float>(ws, wl.off[SAD_WS_G]);
+    const float* Cs = at<float>(ws, wl.off[SAD_WS_CS]);
+    const float* Kk = at<float>(ws, wl.off[SAD_WS_KK]);
+    const float* U = at<float>(ws, wl.off[SAD_WS_U]);
+    const float* CTX = at<float>(ws, wl.off[SAD_WS_CTX]);
+    bf16raw* DZ = at<bf16raw>(ws, wl.off[SAD_WS_DZ]);
+    bf16raw* DX = at<bf16raw>(ws, wl.off[SAD_WS_DX]);
+    float* DU = at<float>(ws, wl.off[SAD_WS_DU]);
+    float* DQ = at<float>(ws, wl.off[SAD_WS_DQ]);
+    float* DHFIN = at<float>(ws, wl.off[SAD_WS_DHFIN]);
+    float* DC = at<float>(ws, wl.off[SAD_WS_DC]);
+
+    // K5'
+    {
+        const float* wa = at<float>(packed, pl.wa);
+        const float* wo = at<float>(packed, pl.wo);
+        const long long* lab = (const long long*)a->labels;
+#define SAD_ATT_BWD(NV)                                                                                            \
+    hipLaunchKernelGGL((k_attn_bwd<NV>), dim3(s.B), dim3(256), 0, st, s, Kk, U, wa, wo, a->weights, CTX, a->logits, \
+                       lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU)
+        if (s.Hp <= 256) SAD_ATT_BWD(1);
+        else if (s.Hp <= 512) SAD_ATT_BWD(2);
+        else if (s.Hp <= 1024) SAD_ATT_BWD(4);
+        else SAD_ATT_BWD(8);
+#undef SAD_ATT_BWD
+        SAD_CHECK_LAUNCH("k_attn_bwd");
+    }
+    // K4': dq = du . W_q ; d[h_fwd | h_rev] = dq . W_hb0
+    {
+        typedef CfgSmall C;
+        dim3 g1(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
+        hipLaunchKernelGGL((k_linear<C, 0>), g1, dim3(C::NT), 0, st, s, s.B, s.Hp, s.Hp, (const void*)DU, s.Hp, lens,
+                           at<bf16raw>(packed, pl.wqT), (const float*)nullptr, DQ, s.Hp);
+        dim3 g2(ceil_div(2 * s.Hp, C::BN), ceil_div(s.B, C::BM));
+        hipLaunchKernelGGL((k_linear<C, 0>), g2, dim3(C::NT), 0, st, s, s.B, 2 * s.Hp, s.Hp, (const void*)DQ, s.Hp, lens,
+                           at<bf16raw>(packed, pl.whb0T), (const float*)nullptr, DHFIN, 2 * s.Hp);
+        SAD_CHECK_LAUNCH("k_linear(bwd)");
+    }
+    // K2': BPTT
+    for (int step = 0; step < s.T; ++step) {
+        typedef CfgSmall C;
+        dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
+        hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whhT), G, Cs,
+                           DHFIN, DC, DZ);
+    }
+    SAD_CHECK_LAUNCH("k_lstm_bwd");
+    // K2a' + K3'
+    if (s.Ep > 128) {
+        typedef CfgWideN C;
+        dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN));
+        hipLaunchKernelGGL((k_inproj_bwd<C>), grid, dim3(C::NT), 0, st, s, DZ, need, at<bf16raw>(packed, pl.wcatT), DX);
+    } else {
+        typedef CfgNarrowN C;
+        dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN));
+        hipLaunchKernelGGL((k_inproj_bwd<C>), grid, dim3(C::NT), 0, st, s, DZ, need, at<bf16raw>(packed, pl.wcatT), DX);
+    }
+    SAD_CHECK_LAUNCH("k_inproj_bwd");
+    // K1'
+    if (a->dsrc != nullptr) {
+        int rc = run_softemb_bwd(s, pl, wl, packed, ws, a->dsrc, a->dsrc_kind, a->dsrc_stride_b, a->dsrc_stride_t, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

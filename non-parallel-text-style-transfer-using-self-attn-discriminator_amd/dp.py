@@ -1,0 +1,62 @@
+"""Batch data-parallel helpers: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
+
+The discriminator step shards over the batch with NO data-path collective in the transfer loop's
+frozen mode: every sentence is independent in the forward and in d(soft tokens),
+so each rank scores its own contiguous slice of the length-sorted batch and keeps its slice of dS.
+The only exchanges are (a) optionally one scalar (the mean loss, for logging) and (b), when the
+discriminator parameters are being trained, one sum all-reduce of the live parameter gradients
+flattened into a single bucket (the reference has no distributed code; this is new in this repo).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(B, rank, world):
+    """Contiguous [lo, hi) slice of a batch of B sentences for `rank` (remainder to low ranks)."""
+    q, r = divmod(B, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_batch(rank, world, *tensors, dim=0):
+    """Slice every tensor along `dim` to this rank's shard.  A length-sorted batch stays sorted
+    inside each shard, which is all ``pack_padded_sequence`` semantics need."""
+    out = []
+    for t in tensors:
+        lo, hi = shard_bounds(t.shape[dim], rank, world)
+        out.append(t.narrow(dim, lo, hi - lo))
+    return out
+
+
+def global_mean_loss(local_loss_sum, local_count):
+    """Mean per-sentence loss over all ranks (one 2-element all-reduce, logging only)."""
+    v = torch.stack([local_loss_sum.detach().float().reshape(()),
+                     torch.as_tensor(float(local_count), device=local_loss_sum.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return v[0] / v[1]
+
+
+def allreduce_grads(params, bucket=None):
+    """Sum-all-reduce the gradients of `params` (those with a grad) as ONE flat fp32 bucket:
+    xGMI is point-to-point, so one large collective beats many small ones.  With the local loss
+    scaled by 1/global_B the summed gradients equal the single-process ``.mean()`` gradients.
+    Returns the flat bucket (reusable across steps)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return bucket
+    n = sum(g.numel() for g in grads)
+    if bucket is None or bucket.numel() != n or bucket.device != grads[0].device:
+        bucket = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+    o = 0
+    for g in grads:
+        bucket[o:o + g.numel()].copy_(g.reshape(-1))
+        o += g.numel()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    o = 0
+    for g in grads:
+        g.copy_(bucket[o:o + g.numel()].view_as(g))
+        o += g.numel()
+    return bucket

@@ -1,0 +1,256 @@
+"""torch.autograd bridge to libsad.so.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); every arithmetic step of the
+discriminator runs in the hand-written HIP kernels behind the C-ABI of include/sad.h.
+
+    pw = pack_weights(named_params, V, E, H, L)                    # fp32 state_dict -> packed image
+    logits, weights = discriminator(src, src_len, mask, pw, soft=True)            # module API
+    loss, logits, weights = discriminator_loss(src, src_len, mask, labels, pw)    # fused CE
+
+``src`` is ``[B,T,V]`` soft tokens (fp32/bf16, any batch/time strides with a contiguous vocabulary
+axis — e.g. the transfer loop's ``sorted_soft_out.transpose(0,1)``, reference
+transfer/models.py:1186) or ``[B,T]`` int64 ids.  The bool ``mask`` is mutated in place exactly as
+the reference mutates it (transfer/models.py:865-867).
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+_LIVE_PARAMS = (
+    "embedding.weight",
+    "rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0",
+    "rnn.weight_ih_l0_reverse", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0_reverse", "rnn.bias_hh_l0_reverse",
+    "hidden_bridges.0.weight", "hidden_bridges.0.bias",
+    "linear_emb.weight", "linear_emb.bias", "linear_q.weight", "linear_q.bias",
+    "linear_attn.weight", "linear_attn.bias", "output_layer.weight", "output_layer.bias",
+)
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class PackedWeights:
+    """Device image of the discriminator weights in the kernels' layout (bf16, padded to MFMA tile
+    multiples, LSTM gate rows permuted, plus pre-transposed copies for the backward GEMMs)."""
+
+    def __init__(self, V, E, H, L, device):
+        self.V, self.E, self.H, self.L = int(V), int(E), int(H), int(L)
+        self.device = torch.device(device)
+        d = _lib.dims(1, 1, V, E, H, L)
+        nbytes = _lib.load().sad_packed_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            raise RuntimeError("libsad sad_packed_bytes failed: " + _lib.last_error())
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.key = None
+
+    def pack(self, params):
+        """params: mapping name -> fp32 contiguous CUDA tensor (state_dict names)."""
+        w = _lib.SadWeights()
+        keep = []
+
+        def p(name):
+            t = params[name].detach()
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise RuntimeError("parameter %s must be a float32 tensor on the HIP device" % name)
+            t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        w.embedding_weight = p("embedding.weight")
+        for i, sfx in enumerate(("", "_reverse")):
+            w.rnn_weight_ih[i] = p("rnn.weight_ih_l0" + sfx)
+            w.rnn_weight_hh[i] = p("rnn.weight_hh_l0" + sfx)
+            w.rnn_bias_ih[i] = p("rnn.bias_ih_l0" + sfx)
+            w.rnn_bias_hh[i] = p("rnn.bias_hh_l0" + sfx)
+        w.hidden_bridge0_weight = p("hidden_bridges.0.weight")
+        w.hidden_bridge0_bias = p("hidden_bridges.0.bias")
+        w.linear_emb_weight = p("linear_emb.weight")
+        w.linear_emb_bias = p("linear_emb.bias")
+        w.linear_q_weight = p("linear_q.weight")
+        w.linear_q_bias = p("linear_q.bias")
+        w.linear_attn_weight = p("linear_attn.weight")
+        w.linear_attn_bias = p("linear_attn.bias")
+        w.output_layer_weight = p("output_layer.weight")
+        w.output_layer_bias = p("output_layer.bias")
+        d = _lib.dims(1, 1, self.V, self.E, self.H, self.L)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().sad_pack_weights(ctypes.byref(d), ctypes.byref(w), _ptr(self.buf), _stream_ptr()),
+                       "sad_pack_weights")
+        return self
+
+
+def pack_weights(params, V=None, E=None, H=None, L=None):
+    """Build a PackedWeights from a name->tensor mapping (a module's ``state_dict()`` or
+    ``dict(named_parameters())``)."""
+    emb = params["embedding.weight"]
+    V = emb.shape[0] if V is None else V
+    E = emb.shape[1] if E is None else E
+    H = params["rnn.weight_hh_l0"].shape[1] if H is None else H
+    L = params["output_layer.weight"].shape[0] if L is None else L
+    return PackedWeights(V, E, H, L, emb.device).pack(params)
+
+
+def _lengths_to_device(src_len, B, device):
+    """Reference callers pass CPU int16/int32/int64 lengths (transfer/models.py:1172, utils/data.py:84);
+    sortedness is what ``pack_padded_sequence(enforce_sorted=True)`` enforces (transfer/models.py:904)."""
+    if not torch.is_tensor(src_len):
+        src_len = torch.as_tensor(src_len)
+    if src_len.numel() != B:
+        raise RuntimeError("src_len has %d entries for a batch of %d" % (src_len.numel(), B))
+    if not src_len.is_cuda:
+        ln = src_len.to(torch.int64)
+        if B > 1 and bool((ln[1:] > ln[:-1]).any()):
+            raise RuntimeError("`lengths` array must be sorted in decreasing order when `enforce_sorted` is True.")
+        if bool((ln <= 0).any()):
+            raise RuntimeError("Length of all samples has to be greater than 0, but found an element in "
+                               "'lengths' that is <= 0")
+    return src_len.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+
+
+class Workspace:
+    """Per-call activation/scratch buffer (torch caching allocator; libsad itself never allocates)."""
+
+    def __init__(self, d, device):
+        nbytes = _lib.load().sad_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            raise RuntimeError("libsad sad_workspace_bytes failed: " + _lib.last_error())
+        self.d = d
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def view(self, name, dtype):
+        off, nb = _lib.workspace_field(self.d, name)
+        return self.buf[off:off + nb].view(dtype)
+
+
+def _src_kind(src):
+    if src.dim() == 2:
+        if src.dtype != torch.int64:
+            raise RuntimeError("token ids must be int64, got %s" % src.dtype)
+        return _lib.SRC_IDS
+    if src.dim() != 3:
+        raise RuntimeError("src must be [B,T] ids or [B,T,V] soft tokens")
+    if src.dtype == torch.float32:
+        return _lib.SRC_F32
+    if src.dtype == torch.bfloat16:
+        return _lib.SRC_BF16
+    raise RuntimeError("soft tokens must be float32 or bfloat16, got %s" % src.dtype)
+
+
+def _is_dense(shape, strides):
+    """True if (shape, strides) is a permutation of a contiguous layout with a unit vocabulary stride."""
+    if strides[-1] != 1:
+        return False
+    order = sorted(range(len(shape)), key=lambda i: strides[i])
+    expect = 1
+    for i in order:
+        if shape[i] != 1 and strides[i] != expect:
+            return False
+        expect *= shape[i]
+    return True
+
+
+class _Discriminator(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, lengths_dev, mask, labels, pw, guard):
+        if not src.is_cuda:
+            raise RuntimeError("sad_amd runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
+        kind = _src_kind(src)
+        B, T = src.shape[0], src.shape[1]
+        if kind != _lib.SRC_IDS:
+            if src.shape[2] != pw.V:
+                raise RuntimeError("soft tokens have vocabulary %d, weights %d" % (src.shape[2], pw.V))
+            if src.stride(2) != 1:
+                src = src.contiguous()
+        if mask.dtype != torch.bool or mask.shape != (B, T) or mask.device != src.device:
+            raise RuntimeError("mask must be a bool [B,T] tensor on the same device as src")
+        dev = src.device
+        d = _lib.dims(B, T, pw.V, pw.E, pw.H, pw.L)
+        ws = Workspace(d, dev)
+        logits = torch.empty((B, pw.L), dtype=torch.float32, device=dev)
+        weights = torch.empty((B, T), dtype=torch.float32, device=dev)
+        loss = torch.empty((B,), dtype=torch.float32, device=dev) if labels is not None else None
+        if labels is not None:
+            labels = labels.to(device=dev, dtype=torch.int64).contiguous()
+        a = _lib.SadFwdArgs()
+        a.src, a.src_kind = src.data_ptr(), kind
+        a.src_stride_b, a.src_stride_t = src.stride(0), src.stride(1)
+        a.lengths = lengths_dev.data_ptr()
+        a.mask, a.mask_stride_b, a.mask_stride_t = mask.data_ptr(), mask.stride(0), mask.stride(1)
+        a.guard = 1 if guard else 0
+        a.labels = labels.data_ptr() if labels is not None else None
+        a.logits, a.weights = logits.data_ptr(), weights.data_ptr()
+        a.loss = loss.data_ptr() if loss is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().sad_forward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
+                                               _stream_ptr()), "sad_forward")
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*([] if kind != _lib.SRC_IDS else [logits, weights] + ([loss] if loss is not None else [])))
+        ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype, labels, logits, weights)
+        ctx.last_ws = ws
+        _Discriminator.last_workspace = ws   # introspection hook for tests / profiling
+        if loss is None:
+            return logits, weights
+        return logits, weights, loss
+
+    @staticmethod
+    def backward(ctx, dlogits, dweights, dloss=None):
+        d, ws, pw, kind, shape, strides, dtype, labels, logits, weights = ctx.sad
+        if kind == _lib.SRC_IDS:
+            return None, None, None, None, None, None
+        dev = logits.device
+        B, T, V = shape
+        if dlogits is not None and dloss is not None:
+            p = torch.softmax(logits, dim=1)
+            p[torch.arange(B, device=dev), labels] -= 1.0
+            dlogits = dlogits + p * dloss.unsqueeze(1)
+            dloss = None
+        if dlogits is None and dloss is None:
+            if dweights is None:
+                return None, None, None, None, None, None
+            dlogits = torch.zeros_like(logits)
+        # dS keeps the memory layout of S (time-major in the transfer loop) so the generator's
+        # autograd consumes it without a transposing copy.
+        if _is_dense(shape, strides):
+            dsrc = torch.empty_strided(shape, strides, dtype=dtype, device=dev)
+        else:
+            dsrc = torch.empty(shape, dtype=dtype, device=dev)
+        a = _lib.SadBwdArgs()
+        a.dlogits = dlogits.contiguous().data_ptr() if dlogits is not None else None
+        keep = dlogits
+        a.labels = labels.data_ptr() if labels is not None else None
+        if dloss is not None:
+            dloss = dloss.to(torch.float32).contiguous()
+            a.dloss = dloss.data_ptr()
+        a.dloss_scale = 0.0
+        if dweights is not None:
+            dweights = dweights.to(torch.float32).contiguous()
+            a.dweights = dweights.data_ptr()
+        a.logits, a.weights = logits.data_ptr(), weights.data_ptr()
+        a.dsrc, a.dsrc_kind = dsrc.data_ptr(), kind
+        a.dsrc_stride_b, a.dsrc_stride_t = dsrc.stride(0), dsrc.stride(1)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().sad_backward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
+                                                _stream_ptr()), "sad_backward")
+        del keep
+        return dsrc, None, None, None, None, None
+
+
+def discriminator(src, src_len, mask, pw, guard=True):
+    """(logits [B,L], attention weights [B,T]) — the reference module's return value."""
+    lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
+    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard)
+
+
+def discriminator_loss(src, src_len, mask, labels, pw, guard=True):
+    """(per-sentence CE loss [B], logits, weights) with the cross entropy fused into the attention
+    kernels — what the transfer step computes at reference transfer/models.py:1185-1212."""
+    lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
+    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard)
+    return loss, logits, weights

@@ -1,0 +1,127 @@
+"""ctypes binding of libsad.so (the C-ABI declared in include/sad.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/build.sh`` into
+``<package>/_native/libsad.so``.  There is no fallback: if the library is missing, every entry point
+raises ``RuntimeError`` (the product path never routes through the oracle or through stock torch
+ops).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_native", "libsad.so")
+
+SRC_IDS, SRC_F32, SRC_BF16 = 0, 1, 2
+
+WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", "DX", "DU", "DQ",
+             "DHFIN", "DC")
+
+# every symbol include/sad.h declares (tests/test_cabi.py checks the .so exports all of them)
+EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",
+           "sad_workspace_bytes", "sad_workspace_field", "sad_pack_weights", "sad_forward",
+           "sad_backward", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd")
+
+
+class SadDims(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "T", "V", "E", "H", "L")]
+
+
+class SadWeights(ctypes.Structure):
+    _fields_ = [
+        ("embedding_weight", c_void_p),
+        ("rnn_weight_ih", c_void_p * 2),
+        ("rnn_weight_hh", c_void_p * 2),
+        ("rnn_bias_ih", c_void_p * 2),
+        ("rnn_bias_hh", c_void_p * 2),
+        ("hidden_bridge0_weight", c_void_p),
+        ("hidden_bridge0_bias", c_void_p),
+        ("linear_emb_weight", c_void_p),
+        ("linear_emb_bias", c_void_p),
+        ("linear_q_weight", c_void_p),
+        ("linear_q_bias", c_void_p),
+        ("linear_attn_weight", c_void_p),
+        ("linear_attn_bias", c_void_p),
+        ("output_layer_weight", c_void_p),
+        ("output_layer_bias", c_void_p),
+    ]
+
+
+class SadFwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("src", c_void_p), ("src_kind", c_int32), ("src_stride_b", c_int64), ("src_stride_t", c_int64),
+        ("lengths", c_void_p),
+        ("mask", c_void_p), ("mask_stride_b", c_int64), ("mask_stride_t", c_int64), ("guard", c_int32),
+        ("labels", c_void_p),
+        ("logits", c_void_p), ("weights", c_void_p), ("loss", c_void_p),
+    ]
+
+
+class SadBwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("dlogits", c_void_p), ("labels", c_void_p), ("dloss", c_void_p), ("dloss_scale", c_float),
+        ("dweights", c_void_p), ("logits", c_void_p), ("weights", c_void_p),
+        ("dsrc", c_void_p), ("dsrc_kind", c_int32), ("dsrc_stride_b", c_int64), ("dsrc_stride_t", c_int64),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libsad.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsad.so not found at %s — the HIP extension is required (no CPU/eager fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`bash <package>/csrc/build.sh`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sad_version.restype = c_int
+    lib.sad_last_error.restype = c_char_p
+    lib.sad_padded_dims.argtypes = [POINTER(SadDims), POINTER(c_int32 * 5)]
+    lib.sad_packed_bytes.argtypes = [POINTER(SadDims)]
+    lib.sad_packed_bytes.restype = c_size_t
+    lib.sad_workspace_bytes.argtypes = [POINTER(SadDims)]
+    lib.sad_workspace_bytes.restype = c_size_t
+    lib.sad_workspace_field.argtypes = [POINTER(SadDims), c_int, POINTER(c_size_t), POINTER(c_size_t)]
+    lib.sad_pack_weights.argtypes = [POINTER(SadDims), POINTER(SadWeights), c_void_p, c_void_p]
+    lib.sad_forward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadFwdArgs), c_void_p, c_void_p]
+    lib.sad_backward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadBwdArgs), c_void_p, c_void_p]
+    lib.sad_prep.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]
+    lib.sad_softemb_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]
+    lib.sad_softemb_bwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]
+    for name in EXPORTS:
+        getattr(lib, name)   # AttributeError here = header/library drift
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sad_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """Map a negative return code to the RuntimeError the reference's callers catch
+    (reference classifier/trainers.py:375-382 special-cases 'out of memory' in the message)."""
+    if rc != 0:
+        raise RuntimeError("libsad %s failed (%d): %s" % (what, rc, last_error()))
+
+
+def dims(B, T, V, E, H, L):
+    return SadDims(int(B), int(T), int(V), int(E), int(H), int(L))
+
+
+def padded_dims(d):
+    out = (c_int32 * 5)()
+    check(load().sad_padded_dims(ctypes.byref(d), ctypes.byref(out)), "sad_padded_dims")
+    return dict(Ep=out[0], Hp=out[1], Gp=out[2], Vp=out[3], Ncat=out[4])
+
+
+def workspace_field(d, name):
+    off, nb = c_size_t(), c_size_t()
+    check(load().sad_workspace_field(ctypes.byref(d), WS_FIELDS.index(name), ctypes.byref(off), ctypes.byref(nb)),
+          "sad_workspace_field")
+    return off.value, nb.value

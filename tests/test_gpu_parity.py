@@ -1,0 +1,262 @@
+"""GPU parity tests: libsad (through the C-ABI, via the ctypes binding) vs the oracle and the golden
+fixtures generated from the reference.  Run on a real MI355X: ``pytest -m gpu``.
+
+Stated tolerances (scale-aware max error, |a-b|_max / |b|_max):
+  * the kernels multiply in bf16 with fp32 accumulation (weights and GEMM-input activations are
+    rounded to bf16, gates/cell state/softmax stay fp32) — BASELINE.json's "bf16" configuration;
+  * BF16_TOL_FWD = 3e-2 for logits / attention weights / loss, BF16_TOL_BWD = 6e-2 for d(soft
+    tokens) against the fp32/fp64 REFERENCE outputs;
+  * token / mask indexing (mask mutation, need bits, zero rows of dS, padding) is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import sad_oracle as O
+from sad_amd import synth
+from tests.util import bf16_round, load_golden, relerr, run_sad, stage_errors
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL_FWD = 3e-2
+BF16_TOL_BWD = 6e-2
+
+
+def _report(title, errs):
+    print("\n[%s]" % title)
+    for k, v in errs.items():
+        print("   %-12s %.3e" % (k, v))
+
+
+def _oracle(params, S_bt, lengths, mask, labels, soft=True, dloss=None, dweights=None, guard=True):
+    p = O.cast_params(params, np.float64)
+    f = O.forward(p, S_bt.astype(np.float64) if soft else S_bt, lengths, mask.copy(), soft, labels=labels, guard=guard)
+    B = len(labels)
+    dl = O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B) if dloss is None else dloss)
+    b = O.backward(p, f["cache"], dl, dweights=dweights)
+    return f, b
+
+
+def test_stages_tiny_exact_inputs():
+    """Every workspace stage against the oracle on inputs that are exactly representable in bf16
+    (one-hot S, bf16-rounded weights): the GEMM stages must then agree to fp32-accumulate accuracy,
+    which separates indexing bugs (O(1)) from rounding (1e-3)."""
+    V, E, H, B, T = 41, 10, 8, 6, 9
+    lengths = np.array([9, 7, 5, 3, 2, 2], dtype=np.int32)
+    params = {k: bf16_round(v) for k, v in synth.make_params(V, E, H, seed=11).items()}
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=5, kind="onehot", time_major=False)
+    labels = synth.make_labels(B, seed=3)
+    mask = synth.transfer_mask(lengths, T)
+    out = run_sad(params, S, lengths, mask, labels, want_ws=True)
+    f, b = _oracle(params, S, lengths, mask, labels)
+    errs = stage_errors(out["ws"], f, b, H, E)
+    errs["logits"] = relerr(out["logits"], f["logits"])
+    errs["weights"] = relerr(out["weights"], f["weights"])
+    errs["loss"] = relerr(out["loss"], f["loss"])
+    errs["dS"] = relerr(out["dS"], b["dS"])
+    _report("tiny exact-input stages", errs)
+    assert np.array_equal(out["ws"]["LENS"], lengths)
+    need = (np.arange(T)[:, None] < lengths[None, :]) * 1 + (~f["cache"]["mask"].T) * 2
+    assert np.array_equal(out["ws"]["NEED"], need.astype(np.uint8))
+    assert errs["X"] == 0.0                      # exact gather through the GEMM
+    for k in ("G0", "G1", "KK"):
+        assert errs[k] < 2e-2, k                 # h is bf16 inside the recurrence
+    assert errs["DX_pad"] == 0.0 and errs["DZ_inactive"] == 0.0
+    for k, v in errs.items():
+        assert v < 5e-2, (k, v)
+
+
+@pytest.mark.parametrize("kind", ["dense", "onehot"])
+@pytest.mark.parametrize("time_major", [True, False])
+def test_tiny_golden(kind, time_major):
+    hdr, d, params, _ = load_golden("tiny_soft_%s_f32.npz" % kind)
+    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2))
+    out = run_sad(params, S_bt, d["lengths"], d["mask"], d["labels"], time_major=time_major, want_ws=True)
+    f, b = _oracle(params, S_bt, d["lengths"], d["mask"], d["labels"])
+    _report("tiny golden %s tm=%s stages" % (kind, time_major), stage_errors(out["ws"], f, b, hdr["H"], hdr["E"]))
+    # bit-exact mask semantics incl. in-place mutation of the caller's tensor
+    assert np.array_equal(out["mask_after"], d["mask_after"])
+    errs = dict(logits=relerr(out["logits"], d["logits"]), weights=relerr(out["weights"], d["weights"]),
+                loss=relerr(out["loss"], d["loss"]), dS=relerr(out["dS"].transpose(1, 0, 2), d["dS"]))
+    _report("tiny golden %s tm=%s" % (kind, time_major), errs)
+    assert errs["logits"] < BF16_TOL_FWD and errs["weights"] < BF16_TOL_FWD and errs["loss"] < BF16_TOL_FWD
+    assert errs["dS"] < BF16_TOL_BWD
+    assert out["dS_strides"] == out["S_strides"]          # dS keeps the layout of S
+    for bi, ln in enumerate(d["lengths"]):
+        assert np.all(out["dS"][bi, ln:] == 0)            # exact zeros on padded steps
+        assert np.all(out["weights"][bi][d["mask_after"][bi]] == 0)
+
+
+def test_tiny_unfused_loss_and_dweights():
+    """Module-style use: logits returned, CE taken by torch, plus an upstream gradient on the
+    attention weights (dlogits / dweights inputs of sad_backward)."""
+    hdr, d, params, _ = load_golden("tiny_soft_dense_f32.npz")
+    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2))
+    B, T = S_bt.shape[:2]
+    dw = np.random.RandomState(0).standard_normal((B, T)).astype(np.float32) * 0.1
+    out = run_sad(params, S_bt, d["lengths"], d["mask"], d["labels"], fused_loss=False, dweights=dw)
+    f, b = _oracle(params, S_bt, d["lengths"], d["mask"], d["labels"], dweights=dw.astype(np.float64))
+    errs = dict(logits=relerr(out["logits"], f["logits"]), dS=relerr(out["dS"], b["dS"]))
+    _report("tiny unfused + dweights", errs)
+    assert errs["logits"] < BF16_TOL_FWD and errs["dS"] < BF16_TOL_BWD
+
+
+@pytest.mark.parametrize("kind", ["dense", "onehot"])
+@pytest.mark.parametrize("s_dtype", ["f32", "bf16"])
+def test_yelp_soft_b8_golden(kind, s_dtype):
+    """Transfer-shaped call at Yelp dims (B=8, T=23, V=9353, E=300, H=512): golden logits /
+    weights / loss / dS samples + checksums from the reference."""
+    hdr, d, _, _ = load_golden("yelp_soft_%s_f32.npz" % kind)
+    V, E, H, B, T = (hdr[k] for k in "VEHBT")
+    params = synth.make_params(V, E, H, seed=hdr["param_seed"])
+    S = synth.make_soft_tokens(B, T, V, d["lengths"], seed=hdr["s_seed"], kind=kind, time_major=False)
+    out = run_sad(params, S, d["lengths"], d["mask"], d["labels"], s_dtype=s_dtype, want_ws=True)
+    f, b = _oracle(params, S, d["lengths"], d["mask"], d["labels"])
+    _report("yelp b8 %s %s stages" % (kind, s_dtype), stage_errors(out["ws"], f, b, H, E))
+    assert np.array_equal(out["mask_after"], d["mask_after"])
+    dS = out["dS"].transpose(1, 0, 2)     # golden is [T,B,V]
+    errs = dict(logits=relerr(out["logits"], d["logits"]), weights=relerr(out["weights"], d["weights"]),
+                loss=relerr(out["loss"], d["loss"]),
+                dS_sample=relerr(dS[:, :, ::hdr["dS_col_stride"]], d["dS_sample"]),
+                dS_rowsum=relerr(dS.astype(np.float64).sum(axis=2), d["dS_rowsum"]),
+                dS_rowsq=relerr((dS.astype(np.float64) ** 2).sum(axis=2), d["dS_rowsq"]),
+                dS_full_vs_oracle=relerr(out["dS"], b["dS"]))
+    _report("yelp b8 %s %s" % (kind, s_dtype), errs)
+    assert errs["logits"] < BF16_TOL_FWD and errs["weights"] < BF16_TOL_FWD and errs["loss"] < BF16_TOL_FWD
+    tol_b = BF16_TOL_BWD if s_dtype == "f32" else BF16_TOL_BWD * 1.5   # + bf16 rounding of dS itself
+    assert errs["dS_sample"] < tol_b and errs["dS_full_vs_oracle"] < tol_b
+    assert errs["dS_rowsq"] < 2 * tol_b
+    for bi, ln in enumerate(d["lengths"]):
+        assert np.all(out["dS"][bi, ln:] == 0)
+
+
+def test_yelp_hard_b64_golden():
+    """Hard-token path on real Yelp sentences (both copies of the reference agree on it)."""
+    hdr, d, _, _ = load_golden("yelp_hard_b64.npz")
+    params = synth.make_params(hdr["V"], hdr["E"], hdr["H"], seed=hdr["param_seed"])
+    out = run_sad(params, d["ids"], d["lengths"], d["mask"], d["labels"], soft=False)
+    errs = dict(logits=relerr(out["logits"], d["logits_f32"]), weights=relerr(out["weights"], d["weights_f32"]),
+                loss=relerr(out["loss"], d["loss_f32"]))
+    _report("yelp hard b64", errs)
+    assert all(v < BF16_TOL_FWD for v in errs.values())
+    assert np.all(out["weights"][d["mask"]] == 0)
+
+
+def test_module_dropin_both_flavours():
+    """The nn.Module mirrors: same state_dict keys as the fixtures' parameter set, transfer and
+    classifier forward signatures, get_masked_src (bit-exact index output)."""
+    import torch
+    from types import SimpleNamespace
+    from sad_amd import classifier_models, transfer_models
+    hdr, d, params, _ = load_golden("tiny_hard_f64.npz")
+    V, E, H = hdr["V"], hdr["E"], hdr["H"]
+    cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0, enc_num_layers=1,
+                          hidden_size=H, vocab_size=V, emb_size=E, num_labels=2, freeze_embedding=False,
+                          device="cuda:0", mask_id=None)
+    sd = {k: torch.from_numpy(v.astype(np.float32)) for k, v in params.items()}
+    mt = transfer_models.SelfAttnRNNClassifier(cfg)
+    assert list(mt.state_dict().keys()) == list(params.keys())
+    mt.load_state_dict(sd)
+    mt.to("cuda:0")
+    for p in mt.parameters():
+        p.requires_grad = False
+    ids = torch.from_numpy(d["ids"]).cuda()
+    mask = torch.from_numpy(d["mask"].copy()).cuda()
+    logits, w = mt(ids, torch.from_numpy(d["lengths"]), mask)
+    assert np.array_equal(mask.cpu().numpy(), d["mask_after"])
+    assert relerr(logits.cpu().numpy(), d["logits"]) < BF16_TOL_FWD
+    assert relerr(w.cpu().numpy(), d["weights"]) < BF16_TOL_FWD
+
+    mc = classifier_models.SelfAttnRNNClassifier(cfg)
+    mc.load_state_dict(sd)
+    mc.to("cuda:0").eval()
+    keep = d["cls_keep"]
+    idk = torch.from_numpy(d["ids"][keep]).cuda()
+    with torch.no_grad():
+        lg, w2 = mc(idk, torch.from_numpy(d["lengths"][keep]), idk == 0)
+        assert relerr(lg.cpu().numpy(), d["cls_logits"]) < BF16_TOL_FWD
+        assert relerr(w2.cpu().numpy(), d["cls_weights"]) < BF16_TOL_FWD
+        mc.set_mask_id(hdr["mask_id"])
+        _, alpha, style_src, content_src = mc.get_masked_src(idk, torch.from_numpy(d["lengths"][keep]), idk == 0)
+    # the threshold split is exact unless a weight sits within bf16 noise of 1/(len-2)
+    thr = 1.0 / (d["lengths"][keep] - 2.0)
+    margin = np.abs(d["cls_weights"] - thr[:, None]).min()
+    if margin > 0.05:
+        assert np.array_equal(style_src.cpu().numpy(), d["gms_style_src"])
+        assert np.array_equal(content_src.cpu().numpy(), d["gms_content_src"])
+    # unfrozen parameters with grad enabled are refused loudly, not silently mistrained
+    for p in mt.parameters():
+        p.requires_grad = True
+    with pytest.raises(NotImplementedError):
+        mt(ids, torch.from_numpy(d["lengths"]), mask)
+
+
+def _cfg3_inputs(B, T=32, V=9353, seed=1234):
+    lengths = synth.make_lengths(B, T, seed=seed)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=seed, kind="dense", time_major=False)
+    return lengths, S, synth.transfer_mask(lengths, T), synth.make_labels(B, seed=seed)
+
+
+def test_cfg3_subsample_vs_oracle_and_shard_invariance():
+    """BASELINE config-3 shape (T=32, V=9353, E=300, H=512) at B=256 in bf16 soft tokens:
+      * 12 sentences spread over the batch are checked against the oracle run on just those
+        sentences (sentences are independent);
+      * size-independent properties: attention weights sum to 1 and vanish under the mask, dS rows
+        are exactly zero for t >= len, scaling dloss by 2 scales dS by exactly 2 (linearity,
+        bit-exact), and scoring the two halves of the batch separately (what 2-GPU data
+        parallelism does) reproduces the full-batch result bit for bit."""
+    B, T, V, E, H = 256, 32, 9353, 300, 512
+    params = synth.make_params(V, E, H, seed=21)
+    lengths, S, mask, labels = _cfg3_inputs(B)
+    S = bf16_round(S)      # the bf16 input path sees exactly these values
+    full = run_sad(params, S, lengths, mask, labels, s_dtype="bf16")
+    sel = np.linspace(0, B - 1, 12).astype(int)
+    f, b = _oracle(params, S[sel], lengths[sel], mask[sel], labels[sel], dloss=np.full((12,), 1.0 / B))
+    errs = dict(logits=relerr(full["logits"][sel], f["logits"]), weights=relerr(full["weights"][sel], f["weights"]),
+                loss=relerr(full["loss"][sel], f["loss"]), dS=relerr(full["dS"][sel], b["dS"]))
+    _report("cfg3 B=256 subsample vs oracle", errs)
+    assert errs["logits"] < BF16_TOL_FWD and errs["weights"] < BF16_TOL_FWD and errs["loss"] < BF16_TOL_FWD
+    assert errs["dS"] < BF16_TOL_BWD * 1.5
+    assert np.allclose(full["weights"].sum(axis=1), 1.0, atol=1e-5)
+    assert np.all(full["weights"][full["mask_after"]] == 0)
+    for bi, ln in enumerate(lengths):
+        assert np.all(full["dS"][bi, ln:] == 0)
+    twice = run_sad(params, S, lengths, mask, labels, s_dtype="bf16", dloss=np.full((B,), 2.0 / B))
+    assert np.array_equal(twice["dS"], 2.0 * full["dS"])
+    h = B // 2
+    for lo, hi in ((0, h), (h, B)):
+        part = run_sad(params, S[lo:hi], lengths[lo:hi], mask[lo:hi], labels[lo:hi], s_dtype="bf16",
+                       dloss=np.full((hi - lo,), 1.0 / B))
+        assert np.array_equal(part["logits"], full["logits"][lo:hi])
+        assert np.array_equal(part["weights"], full["weights"][lo:hi])
+        assert np.array_equal(part["dS"], full["dS"][lo:hi])
+
+
+def test_ragged_and_edge_shapes():
+    """Edge cases: B=1, all lengths equal to T, len==2 rows (all-masked guard), a batch and T that
+    are not multiples of any tile size, unsorted lengths given on the device (no host check)."""
+    import torch
+    V, E, H = 203, 36, 40
+    params = synth.make_params(V, E, H, seed=5)
+    for B, T, lens in ((1, 4, [4]), (5, 7, [7] * 5), (3, 5, [2, 2, 2]), (67, 33, None)):
+        lengths = synth.make_lengths(B, T, seed=B) if lens is None else np.array(lens, np.int32)
+        S = synth.make_soft_tokens(B, T, V, lengths, seed=B, kind="dense", time_major=False)
+        mask = synth.transfer_mask(lengths, T)
+        labels = synth.make_labels(B, seed=B)
+        out = run_sad(params, S, lengths, mask, labels)
+        f, b = _oracle(params, S, lengths, mask, labels)
+        errs = dict(logits=relerr(out["logits"], f["logits"]), weights=relerr(out["weights"], f["weights"]),
+                    dS=relerr(out["dS"], b["dS"]))
+        _report("edge B=%d T=%d" % (B, T), errs)
+        assert np.array_equal(out["mask_after"], f["cache"]["mask"])
+        assert errs["logits"] < BF16_TOL_FWD and errs["weights"] < BF16_TOL_FWD and errs["dS"] < BF16_TOL_BWD
+    # error paths surface as RuntimeError (what the reference's trainers catch)
+    from sad_amd import functional as Fn
+    pw = Fn.pack_weights({k: torch.from_numpy(v).cuda() for k, v in params.items()})
+    S = torch.zeros(2, 3, V, device="cuda")
+    m = torch.zeros(2, 3, dtype=torch.bool, device="cuda")
+    with pytest.raises(RuntimeError):
+        Fn.discriminator(S, torch.tensor([2, 3]), m, pw)        # unsorted CPU lengths
+    with pytest.raises(RuntimeError):
+        Fn.discriminator(S.cpu(), torch.tensor([3, 2]), m, pw)  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        Fn.discriminator(torch.zeros(2, 3, V + 1, device="cuda"), torch.tensor([3, 2]), m, pw)

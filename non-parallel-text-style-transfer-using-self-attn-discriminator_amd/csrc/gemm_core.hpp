@@ -7,18 +7,20 @@
 //    CONSECUTIVE columns n = (l >> 4) * 4 + {0..3} of each 16x16 tile.  Epilogues therefore store
 //    8/16 contiguous bytes per lane along n, and the LSTM epilogue finds the four gates of one
 //    hidden unit in acc[tm][0..3] of the same lane (see gate_col()).
-//  * global -> register -> LDS staging, split so the next tile's global loads are in flight while
-//    the MFMAs of the current tile run; LDS rows padded by 16 B (row stride 144 B).
+//  * global -> register -> LDS staging with NS K-tiles of global loads in flight (register ring,
+//    statically indexed); LDS rows padded by 16 B (row stride 144 B).
 //  * Operand access goes through loader functors so each op decides dtype conversion (fp32 soft
 //    tokens -> bf16), row predicates (sequence length masks), gathers and bounds.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace sad {
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int NS_ = 1>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, BK = 64, WM = WM_, WN = WN_;
+    static constexpr int NS = NS_;                          // K-tiles of global loads kept in flight
     static constexpr int NT = 64 * WM_ * WN_;               // threads per workgroup
     static constexpr int TM = BM_ / WM_ / 16;               // 16x16 tiles per wave along m
     static constexpr int TN = BN_ / WN_ / 16;               // ... along n
@@ -37,6 +39,14 @@ __device__ __forceinline__ int frag_row(int wm, int tm, int lane) { return wm * 
 template <class C>
 __device__ __forceinline__ int frag_col(int wn, int tn, int lane) { return wn * (C::BN / C::WN) + tn * 16 + (lane >> 4) * 4; }
 
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 // load_a(i, r, k) -> ARaw : chunk i of this thread = tile row r, 8 elements starting at absolute k
 // cvt_a(ARaw)     -> u32x4 (8 bf16)
 // load_b(i, r, k) -> u32x4
@@ -46,38 +56,34 @@ __device__ __forceinline__ void gemm_core(int K, LA load_a, CA cvt_a, LB load_b,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int r0 = tid / C::CH, kc = (tid % C::CH) * 8;
-    ARaw ra[C::ACH];
-    u32x4 rb[C::BCH];
+    ARaw ra[C::NS][C::ACH];
+    u32x4 rb[C::NS][C::BCH];
     const int nk = (K + C::BK - 1) / C::BK;
 
+    auto issue = [&](auto stage, int kt) {
+        constexpr int s = decltype(stage)::value;
+        const int k0 = kt * C::BK + kc;
 #pragma unroll
-    for (int i = 0; i < C::ACH; ++i) ra[i] = load_a(i, r0 + i * C::RSTEP, kc);
+        for (int i = 0; i < C::ACH; ++i) ra[s][i] = load_a(i, r0 + i * C::RSTEP, k0);
 #pragma unroll
-    for (int i = 0; i < C::BCH; ++i) rb[i] = load_b(i, r0 + i * C::RSTEP, kc);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();   // every wave is done reading the previous tile
+        for (int i = 0; i < C::BCH; ++i) rb[s][i] = load_b(i, r0 + i * C::RSTEP, k0);
+    };
+    auto stage_to_lds = [&](auto stage) {
+        constexpr int s = decltype(stage)::value;
+        __syncthreads();                       // every wave is done reading the previous tile
 #pragma unroll
-        for (int i = 0; i < C::ACH; ++i)
-            *(u32x4*)&As[(r0 + i * C::RSTEP) * C::LDT + kc] = cvt_a(ra[i]);
+        for (int i = 0; i < C::ACH; ++i) *(u32x4*)&As[(r0 + i * C::RSTEP) * C::LDT + kc] = cvt_a(ra[s][i]);
 #pragma unroll
-        for (int i = 0; i < C::BCH; ++i)
-            *(u32x4*)&Bs[(r0 + i * C::RSTEP) * C::LDT + kc] = rb[i];
+        for (int i = 0; i < C::BCH; ++i) *(u32x4*)&Bs[(r0 + i * C::RSTEP) * C::LDT + kc] = rb[s][i];
         __syncthreads();
-        if (kt + 1 < nk) {   // next tile's global loads fly under this tile's MFMAs
-            const int k0 = (kt + 1) * C::BK + kc;
-#pragma unroll
-            for (int i = 0; i < C::ACH; ++i) ra[i] = load_a(i, r0 + i * C::RSTEP, k0);
-#pragma unroll
-            for (int i = 0; i < C::BCH; ++i) rb[i] = load_b(i, r0 + i * C::RSTEP, k0);
-        }
+    };
+    auto mfma_tile = [&]() {
 #pragma unroll
         for (int kk = 0; kk < C::BK / 32; ++kk) {
             bf16x8 af[C::TM], bfr[C::TN];
             const int ko = kk * 32 + (lane >> 4) * 8;
 #pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-                af[tm] = *(const bf16x8*)&As[frag_row<C>(wm, tm, lane) * C::LDT + ko];
+            for (int tm = 0; tm < C::TM; ++tm) af[tm] = *(const bf16x8*)&As[frag_row<C>(wm, tm, lane) * C::LDT + ko];
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn)
                 bfr[tn] = *(const bf16x8*)&Bs[(wn * (C::BN / C::WN) + tn * 16 + (lane & 15)) * C::LDT + ko];
@@ -87,6 +93,35 @@ __device__ __forceinline__ void gemm_core(int K, LA load_a, CA cvt_a, LB load_b,
                 for (int tn = 0; tn < C::TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
         }
+    };
+
+    // Prologue: NS K-tiles of global loads in flight (registers are the staging ring; the small
+    // latency-bound GEMMs of the recurrence need several tiles outstanding to cover L2/HBM latency).
+    static_for<C::NS>([&](auto stage) {
+        if (decltype(stage)::value < nk) issue(stage, decltype(stage)::value);
+    });
+    // Steady state: branch-free (the loaders are branch-free too), so hipcc's waitcnt pass keeps
+    // COUNTED s_waitcnt vmcnt(N): only the oldest stage is waited for, NS-1 tiles stay in flight.
+    // (Any control flow around the loads makes it fall back to vmcnt(0) = a one-deep pipeline.)
+    const int steady = nk > C::NS ? (nk - C::NS) / C::NS : 0;      // groups of NS tiles that all refill
+    for (int g = 0; g < steady; ++g) {
+        static_for<C::NS>([&](auto stage) {
+            const int kt = g * C::NS + decltype(stage)::value;
+            stage_to_lds(stage);
+            issue(stage, kt + C::NS);
+            mfma_tile();
+        });
+    }
+    // Drain: at most 2*NS-1 tiles, refilling while tiles remain.
+    for (int kt0 = steady * C::NS; kt0 < nk; kt0 += C::NS) {
+        static_for<C::NS>([&](auto stage) {
+            const int kt = kt0 + decltype(stage)::value;
+            if (kt < nk) {                     // block-uniform
+                stage_to_lds(stage);
+                if (kt + C::NS < nk) issue(stage, kt + C::NS);
+                mfma_tile();
+            }
+        });
     }
 }
 
@@ -98,10 +133,17 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[C::TM][C::TN]) {
         for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// Aligned 16-byte load of 8 bf16 from a packed (padded, 16-B aligned) matrix; zero outside [rows) x [K).
+// Aligned 16-byte load of 8 bf16 from a packed (padded, 16-B aligned) matrix; zero outside
+// [rows) x [K).  Branch-free on purpose (clamped address + select): see the steady-state note above.
 __device__ __forceinline__ u32x4 load_packed(const bf16raw* base, long long ld, int row, int rows, int k, int K) {
-    if (row < rows && k < K) return *(const u32x4*)(base + (long long)row * ld + k);
-    return u32x4{0u, 0u, 0u, 0u};
+    const bool ok = row < rows && k < K;
+    const u32x4 v = *(const u32x4*)(base + (ok ? (long long)row * ld + k : 0ll));
+    return ok ? v : u32x4{0u, 0u, 0u, 0u};
+}
+// Same for a row pointer that may be invalid (`ok` false): `dummy` must be readable for 16 bytes.
+__device__ __forceinline__ u32x4 load_row(const bf16raw* row, bool ok, const bf16raw* dummy, int k) {
+    const u32x4 v = *(const u32x4*)(ok ? row + k : dummy);
+    return ok ? v : u32x4{0u, 0u, 0u, 0u};
 }
 
 struct Ident {

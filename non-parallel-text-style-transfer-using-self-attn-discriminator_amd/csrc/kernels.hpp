@@ -67,6 +67,15 @@ struct SoftRow<SRC_F32> {
     typedef RawF32x8 Raw;
     typedef CvtF32x8 Cvt;
     typedef float Elem;
+    // full chunk, row may be invalid (p == nullptr -> zeros); branch-free
+    static __device__ __forceinline__ Raw load_fast(const float* p, const float* dummy, int k) {
+        const float* q = p != nullptr ? p + k : dummy;
+        Raw r;
+        r.lo = *(const f32x4u*)q;
+        r.hi = *(const f32x4u*)(q + 4);
+        if (p == nullptr) r.lo = r.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+        return r;
+    }
     static __device__ __forceinline__ Raw load(const float* p, int k, int V) {
         Raw r;
         if (p != nullptr && k + 8 <= V) {
@@ -87,6 +96,10 @@ struct SoftRow<SRC_BF16> {
     typedef u32x4 Raw;
     typedef Ident Cvt;
     typedef bf16raw Elem;
+    static __device__ __forceinline__ Raw load_fast(const bf16raw* p, const bf16raw* dummy, int k) {
+        const u32x4 v = *(const u32x4h*)(p != nullptr ? p + k : dummy);
+        return p != nullptr ? v : u32x4{0u, 0u, 0u, 0u};
+    }
     static __device__ __forceinline__ Raw load(const bf16raw* p, int k, int V) {
         if (p != nullptr && k + 8 <= V) return *(const u32x4h*)(p + k);
         unsigned t[8];
@@ -120,9 +133,16 @@ __global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __re
             }
         }
         const int V = s.V, Vp = s.Vp, Ep = s.Ep;
-        gemm_core<C, typename SR::Raw>(
-            V, [&](int i, int, int k) { return SR::load(arow[i], k, V); }, typename SR::Cvt(),
-            [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, k, Vp); }, acc, As, Bs);
+        const int Vmain = V / C::BK * C::BK;     // whole K-tiles: unguarded, branch-free loads
+        const Elem* dummy = (const Elem*)src;
+        if (Vmain > 0)
+            gemm_core<C, typename SR::Raw>(
+                Vmain, [&](int i, int, int k) { return SR::load_fast(arow[i], dummy, k); }, typename SR::Cvt(),
+                [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, k, Vp); }, acc, As, Bs);
+        if (Vmain < V)                           // ragged last tile (V is odd): element-guarded loads
+            gemm_core<C, typename SR::Raw>(
+                V - Vmain, [&](int i, int, int k) { return SR::load(arow[i], Vmain + k, V); }, typename SR::Cvt(),
+                [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, Vmain + k, Vp); }, acc, As, Bs);
     }
     const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(C::NT) void k_inproj_fwd(Shape s, const bf16raw* __
 template <class C>
 __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int* __restrict__ lens,
                                                    const bf16raw* __restrict__ whh, float* __restrict__ G,
-                                                   float* __restrict__ Cs, bf16raw* __restrict__ Hs) {
+                                                   float* __restrict__ Cs, bf16raw* __restrict__ Hs, int dbg) {
     static_assert(C::BN / C::WN == 64 && C::TN == 4, "one 64-column gate block per wave");
     __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
     __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
@@ -219,7 +239,29 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
     f32x4 acc[C::TM][C::TN];
     zero_acc<C>(acc);
     const int Hp = s.Hp, Gp = s.Gp, B = s.B;
-    if (tp_ok) {
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int col0 = n0 + wn * 64;                   // first permuted column of this wave's unit block
+    const int u4 = (lane >> 4) * 4;
+    const int j = (col0 >> 6) * 16 + u4;             // first of this lane's 4 hidden units
+    // Epilogue operands (gate pre-activations, c_prev) are requested BEFORE the GEMM so their HBM
+    // latency hides under the K loop instead of trailing it.
+    f32x4 pre[C::TM][4], cp[C::TM];
+    bool act[C::TM];
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int b = b0 + frag_row<C>(wm, tm, lane);
+        act[tm] = b < B && col0 < Gp && lens[b] > t;
+        cp[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (act[tm] && !(dbg & 4)) {
+            const float* g = G + (((long long)t * B + b) * 2 + dir) * Gp + col0 + u4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[tm][q] = *(const f32x4*)(g + 16 * q);
+            if (tp_ok && lens[b] > tp) cp[tm] = *(const f32x4*)&Cs[(((long long)tp * B + b) * 2 + dir) * Hp + j];
+        }
+    }
+    if (tp_ok && !(dbg & 1)) {
         const bf16raw* arow[C::ACH];
 #pragma unroll
         for (int i = 0; i < C::ACH; ++i) {
@@ -228,29 +270,19 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
         }
         const bf16raw* w = whh + (long long)dir * Gp * Hp;
         gemm_core<C, u32x4>(
-            Hp,
-            [&](int i, int, int k) {
-                return (arow[i] != nullptr && k < Hp) ? *(const u32x4*)(arow[i] + k) : u32x4{0u, 0u, 0u, 0u};
-            },
+            Hp, [&](int i, int, int k) { return load_row(arow[i], arow[i] != nullptr && k < Hp, Hs, k); },
             Ident(), [&](int, int r, int k) { return load_packed(w, Hp, n0 + r, Gp, k, Hp); }, acc, As, Bs);
     }
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int col0 = n0 + wn * 64;                   // first permuted column of this wave's unit block
-    if (col0 >= Gp) return;
-    const int u4 = (lane >> 4) * 4;
-    const int j = (col0 >> 6) * 16 + u4;             // first of this lane's 4 hidden units
 #pragma unroll
     for (int tm = 0; tm < C::TM; ++tm) {
+        if (!act[tm]) continue;
         const int b = b0 + frag_row<C>(wm, tm, lane);
-        if (b >= B || lens[b] <= t) continue;
         const long long row = ((long long)t * B + b) * 2 + dir;
         float* g = G + row * Gp + col0 + u4;
-        const f32x4 pi = acc[tm][0] + *(const f32x4*)(g + 0);
-        const f32x4 pf = acc[tm][1] + *(const f32x4*)(g + 16);
-        const f32x4 pg = acc[tm][2] + *(const f32x4*)(g + 32);
-        const f32x4 po = acc[tm][3] + *(const f32x4*)(g + 48);
-        f32x4 cp = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tp_ok && lens[b] > tp) cp = *(const f32x4*)&Cs[(((long long)tp * B + b) * 2 + dir) * Hp + j];
+        const f32x4 pi = acc[tm][0] + pre[tm][0];
+        const f32x4 pf = acc[tm][1] + pre[tm][1];
+        const f32x4 pg = acc[tm][2] + pre[tm][2];
+        const f32x4 po = acc[tm][3] + pre[tm][3];
         f32x4 gi, gf, gg, go, c, h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -258,13 +290,15 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
             gf[e] = sigmoidf_(pf[e]);
             gg[e] = tanhf_(pg[e]);
             go[e] = sigmoidf_(po[e]);
-            c[e] = gf[e] * cp[e] + gi[e] * gg[e];
+            c[e] = gf[e] * cp[tm][e] + gi[e] * gg[e];
             h[e] = go[e] * tanhf_(c[e]);
         }
-        *(f32x4*)(g + 0) = gi;
-        *(f32x4*)(g + 16) = gf;
-        *(f32x4*)(g + 32) = gg;
-        *(f32x4*)(g + 48) = go;
+        if (!(dbg & 2)) {
+            *(f32x4*)(g + 0) = gi;
+            *(f32x4*)(g + 16) = gf;
+            *(f32x4*)(g + 32) = gg;
+            *(f32x4*)(g + 48) = go;
+        }
         *(f32x4*)&Cs[row * Hp + j] = c;
         *(u32x2*)&Hs[row * Hp + j] = pack_bf16x4(h);
     }
@@ -292,13 +326,12 @@ __global__ __launch_bounds__(C::NT) void k_linear(Shape s, int Mrows, int N, int
             K,
             [&](int, int r, int k) {
                 RawF32x8 v;
-                v.lo = v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int m = m0 + r;
-                if (m < Mrows && k < K) {
-                    const float* p = Af + (long long)m * lda + k;
-                    v.lo = *(const f32x4*)p;
-                    v.hi = *(const f32x4*)(p + 4);
-                }
+                const bool ok = m < Mrows && k < K;
+                const float* p = Af + (ok ? (long long)m * lda + k : 0ll);
+                v.lo = *(const f32x4*)p;
+                v.hi = *(const f32x4*)(p + 4);
+                if (!ok) v.lo = v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
                 return v;
             },
             CvtF32x8(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
@@ -309,12 +342,11 @@ __global__ __launch_bounds__(C::NT) void k_linear(Shape s, int Mrows, int N, int
             K,
             [&](int, int r, int k) {
                 const int b = m0 + r;
-                if (b >= Mrows || k >= K) return u32x4{0u, 0u, 0u, 0u};
                 const int d = k >= Hp ? 1 : 0, kk = k - d * Hp;
-                const int len = lens[b];
-                if (len <= 0) return u32x4{0u, 0u, 0u, 0u};
+                const int len = b < Mrows ? lens[b] : 0;
+                const bool ok = len > 0 && k < K;
                 const int ts = d ? 0 : len - 1;
-                return *(const u32x4*)(Hs + (((long long)ts * B + b) * 2 + d) * Hp + kk);
+                return load_row(Hs + (((long long)ts * B + b) * 2 + d) * Hp, ok, Hs, kk);
             },
             Ident(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
     }
@@ -572,6 +604,38 @@ __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int
     any = __syncthreads_or(any);
     f32x4 acc[C::TM][C::TN];
     zero_acc<C>(acc);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    // Epilogue operands are requested before the GEMM (their latency hides under the K loop).
+    struct Pre {
+        f32x4 gi, gf, gg, go, c, cp, dc, dhf;
+    } pre[C::TM][C::TN];
+    bool act[C::TM];
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int b = b0 + frag_row<C>(wm, tm, lane);
+        const int len = b < B ? lens[b] : 0;
+        act[tm] = len > t;
+        const bool last = dir ? (t == 0) : (t == len - 1);
+        const long long row = ((long long)t * B + b) * 2 + dir;
+#pragma unroll
+        for (int tnn = 0; tnn < C::TN; ++tnn) {
+            Pre& p = pre[tm][tnn];
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            p.gi = p.gf = p.gg = p.go = p.c = p.cp = p.dc = p.dhf = z;
+            const int j = n0 + frag_col<C>(wn, tnn, lane);   // 4 consecutive hidden units
+            if (!act[tm] || j >= Hp) continue;
+            const int pc = (j >> 4) * 64 + (j & 15);         // permuted column of gate 0
+            const float* g = G + row * Gp + pc;
+            p.gi = *(const f32x4*)(g + 0);
+            p.gf = *(const f32x4*)(g + 16);
+            p.gg = *(const f32x4*)(g + 32);
+            p.go = *(const f32x4*)(g + 48);
+            p.c = *(const f32x4*)&Cs[row * Hp + j];
+            if (tpf_ok && len > tpf) p.cp = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + j];
+            if (tn_ok && len > tn) p.dc = *(const f32x4*)&DC[(long long)b * 2 * Hp + dir * Hp + j];
+            if (last) p.dhf = *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + j];
+        }
+    }
     if (any && tn_ok) {
         const bf16raw* arow[C::ACH];
 #pragma unroll
@@ -581,59 +645,43 @@ __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int
         }
         const bf16raw* w = whhT + (long long)dir * Hp * Gp;
         gemm_core<C, u32x4>(
-            Gp,
-            [&](int i, int, int k) {
-                return (arow[i] != nullptr && k < Gp) ? *(const u32x4*)(arow[i] + k) : u32x4{0u, 0u, 0u, 0u};
-            },
+            Gp, [&](int i, int, int k) { return load_row(arow[i], arow[i] != nullptr && k < Gp, DZ, k); },
             Ident(), [&](int, int r, int k) { return load_packed(w, Gp, n0 + r, Hp, k, Gp); }, acc, As, Bs);
     }
-    const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
     for (int tm = 0; tm < C::TM; ++tm) {
         const int b = b0 + frag_row<C>(wm, tm, lane);
         if (b >= B) continue;
-        const int len = lens[b];
-        const bool act = len > t;
-        const bool last = dir ? (t == 0) : (t == len - 1);
-        const long long row = ((long long)t * B + b) * 2 + dir;
         bf16raw* zrow = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
 #pragma unroll
         for (int tnn = 0; tnn < C::TN; ++tnn) {
-            const int j = n0 + frag_col<C>(wn, tnn, lane);   // 4 consecutive hidden units
+            const int j = n0 + frag_col<C>(wn, tnn, lane);
             if (j >= Hp) continue;
-            const int pc = (j >> 4) * 64 + (j & 15);         // permuted column of gate 0
-            if (!act) {
+            const int pc = (j >> 4) * 64 + (j & 15);
+            if (!act[tm]) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) *(u32x2*)&zrow[pc + g * 16] = u32x2{0u, 0u};
                 continue;
             }
-            f32x4 dh = acc[tm][tnn];
-            if (last) dh += *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + j];
-            f32x4 dc = f32x4{0.f, 0.f, 0.f, 0.f}, cp = f32x4{0.f, 0.f, 0.f, 0.f};
-            float* dcp = DC + (long long)b * 2 * Hp + dir * Hp + j;
-            if (tn_ok && len > tn) dc = *(const f32x4*)dcp;
-            if (tpf_ok && len > tpf) cp = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + j];
-            const float* g = G + row * Gp + pc;
-            const f32x4 gi = *(const f32x4*)(g + 0), gf = *(const f32x4*)(g + 16);
-            const f32x4 gg = *(const f32x4*)(g + 32), go = *(const f32x4*)(g + 48);
-            const f32x4 c = *(const f32x4*)&Cs[row * Hp + j];
+            const Pre& p = pre[tm][tnn];
+            const f32x4 dh = acc[tm][tnn] + p.dhf;
             f32x4 zi, zf, zg, zo, dcn;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float tc = tanhf_(c[e]);
+                const float tc = tanhf_(p.c[e]);
                 const float d_o = dh[e] * tc;
-                const float dct = dc[e] + dh[e] * go[e] * (1.f - tc * tc);
-                zi[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
-                zf[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
-                zg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
-                zo[e] = d_o * go[e] * (1.f - go[e]);
-                dcn[e] = dct * gf[e];
+                const float dct = p.dc[e] + dh[e] * p.go[e] * (1.f - tc * tc);
+                zi[e] = dct * p.gg[e] * p.gi[e] * (1.f - p.gi[e]);
+                zf[e] = dct * p.cp[e] * p.gf[e] * (1.f - p.gf[e]);
+                zg[e] = dct * p.gi[e] * (1.f - p.gg[e] * p.gg[e]);
+                zo[e] = d_o * p.go[e] * (1.f - p.go[e]);
+                dcn[e] = dct * p.gf[e];
             }
             *(u32x2*)&zrow[pc + 0] = pack_bf16x4(zi);
             *(u32x2*)&zrow[pc + 16] = pack_bf16x4(zf);
             *(u32x2*)&zrow[pc + 32] = pack_bf16x4(zg);
             *(u32x2*)&zrow[pc + 48] = pack_bf16x4(zo);
-            *(f32x4*)dcp = dcn;
+            *(f32x4*)&DC[(long long)b * 2 * Hp + dir * Hp + j] = dcn;
         }
     }
 }
@@ -720,6 +768,180 @@ __global__ __launch_bounds__(C::NT) void k_softemb_bwd(Shape s, const bf16raw* _
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1' fast path (Ep == 32*KS): A-stationary.  A workgroup owns 256 token rows x a range of
+// 64-column vocabulary tiles.  Each of its 8 waves keeps the dX fragments of its 32 rows for the
+// WHOLE K = Ep in registers (loaded once), the embedding tile [64][Ep] (one contiguous 64*Ep*2-byte
+// block of the packed table) is staged through LDS and shared by all 8 waves, so per output byte
+// the kernel moves ~Ep/256 bytes of operands instead of re-reading both operands per 128x128 tile.
+//   * LDS image: unpadded rows, 16-byte chunks XOR-swizzled with (row>>1)&7 -> conflict-free
+//     ds_read_b128 fragment reads (MI355X bank rule: 64 banks, 16-lane groups).
+//   * LDS row rho holds vocabulary column sigma(rho) (a bit permutation), so that a lane's
+//     accumulator tile pairs are 8 CONSECUTIVE vocabulary entries: 16-/32-byte stores per lane,
+//     64/128 contiguous bytes per token row per store instruction.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int KIND, int DBG = 0>
+__global__ __launch_bounds__(512) void k_softemb_bwd_rs(Shape s, const bf16raw* __restrict__ DX,
+                                                       const unsigned char* __restrict__ need,
+                                                       const bf16raw* __restrict__ wemb, void* __restrict__ dS,
+                                                       long long sT, long long sB, int nt_per) {
+    constexpr int EP = KS * 32, BN = 64, BM = 256, NTH = 512;
+    constexpr int ROWB = EP * 2;              // bytes per embedding row
+    constexpr int CPR = EP / 8;               // 16-byte chunks per row
+    constexpr int SCH = BN * CPR / NTH;       // staging chunks per thread
+    static_assert((BN * CPR) % NTH == 0, "tile must split evenly over the workgroup");
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const int ntiles = s.Vp / BN;
+    const int nt0 = blockIdx.y * nt_per;
+    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
+    const int M = s.M, V = s.V;
+
+    // rows of this lane (two 16-row MFMA tiles of the wave's 32 rows) and their output bases
+    int mrow[2];
+    long long obase[2];
+    int rneed = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = m0 + wave * 32 + tm * 16 + (lane & 15);
+        mrow[tm] = m;
+        obase[tm] = 0;
+        if (m < M) {
+            const int t = m / s.B, b = m - t * s.B;
+            obase[tm] = (long long)t * sT + (long long)b * sB;
+            rneed |= need[m];
+        }
+    }
+    const bool wave_any = __any(rneed != 0);
+    const int block_any = __syncthreads_or(rneed != 0);
+
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(DX + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
+            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+
+    // Retire the fragment loads HERE.  Otherwise they are still "pending" at the loop header and
+    // hipcc's waitcnt pass, merging that state over the back edge, puts s_waitcnt vmcnt(0) in front
+    // of the first MFMA of EVERY tile — draining the previous tile's stores and the prefetch.
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(a[tm][ks]));
+
+    // staging map of this thread: global chunk g -> (vocabulary row vloc, chunk) -> swizzled LDS offset
+    int soff[SCH], goff[SCH];
+#pragma unroll
+    for (int i = 0; i < SCH; ++i) {
+        const int g = tid + i * NTH;
+        const int vloc = g / CPR, ch = g - vloc * CPR;
+        // vloc = 32p + 8g + 4tau + r  <->  rho = 32p + 16tau + 4g + r
+        const int rho = (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3);
+        soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
+        goff[i] = g * 8;                    // elements from the tile's first row (tile is contiguous)
+    }
+    u32x4 st[SCH];
+    auto load_tile = [&](int nt) {
+        const bf16raw* base = wemb + (long long)nt * BN * EP;
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
+    };
+    // fragment read offsets: LDS row rho = tn*16 + (lane&15), chunk = ks*4 + (lane>>4)
+    int roff[4], rsw[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int rho = tn * 16 + (lane & 15);
+        roff[tn] = rho * ROWB;
+        rsw[tn] = (rho >> 1) & 7;
+    }
+    // Pipeline per 64-column tile (ONE LDS buffer):  compute(nt) | barrier | LDS <- tile nt+1 |
+    // barrier | stores(nt) | issue loads(nt+2).  vmcnt retires in order, so the wait in front of the
+    // LDS write also covers the stores of tile nt-1 — which by then had a whole MFMA phase to
+    // drain; the stores of tile nt drain under compute(nt+1).  (Issuing the stores BEFORE the
+    // staging wait would expose the full HBM write latency on every tile.)
+    if (block_any) {
+        load_tile(nt0);
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
+        __syncthreads();
+        if (nt0 + 1 < nt1) load_tile(nt0 + 1);
+    }
+    for (int nt = nt0; nt < nt1; ++nt) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (block_any) {
+            if (wave_any && !(DBG & 2)) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 bfr[4];
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        bfr[tn] = *(const bf16x8*)&Bs[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+                }
+            }
+            if (!(DBG & 4)) __syncthreads();                       // all waves finished reading tile nt
+            if (nt + 1 < nt1 && !(DBG & 4)) {
+#pragma unroll
+                for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
+            }
+            if (!(DBG & 4)) __syncthreads();
+        }
+        // lane owns columns [8g, 8g+8) (tiles 0,1) and [32+8g, 32+8g+8) (tiles 2,3) of the tile: each
+        // store instruction writes 64 contiguous bytes (bf16) / 2 x 64 (fp32) per token row.
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            if (DBG & 1) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) asm volatile("" ::"v"(acc[tm][tn]));
+                continue;
+            }
+            if (mrow[tm] >= M) continue;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int n = nt * BN + 32 * pr + 8 * (lane >> 4);
+                if (n >= V) continue;
+                const f32x4 lo = acc[tm][2 * pr], hi = acc[tm][2 * pr + 1];
+                if constexpr (KIND == SRC_F32) {
+                    float* p = (float*)dS + obase[tm] + n;
+                    if (n + 8 <= V) {
+                        *(f32x4u*)p = lo;
+                        *(f32x4u*)(p + 4) = hi;
+                    } else {
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < V) p[e] = lo[e];
+                            if (n + 4 + e < V) p[4 + e] = hi[e];
+                        }
+                    }
+                } else {
+                    bf16raw* p = (bf16raw*)dS + obase[tm] + n;
+                    if (n + 8 <= V) {
+                        *(u32x4h*)p = pack_bf16x8(lo, hi);
+                    } else {
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < V) p[e] = f32_to_bf16(lo[e]);
+                            if (n + 4 + e < V) p[4 + e] = f32_to_bf16(hi[e]);
+                        }
+                    }
+                }
+            }
+        }
+        if (block_any && nt + 2 < nt1 && !(DBG & 4)) load_tile(nt + 2);
     }
 }
 

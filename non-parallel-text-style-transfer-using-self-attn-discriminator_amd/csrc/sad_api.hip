@@ -5,6 +5,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace sad;
@@ -119,11 +120,14 @@ int check_aligned(const void* p, size_t a, const char* name) {
     return 0;
 }
 
-typedef Cfg<128, 320, 2, 4> CfgWideN;   // 512 threads; all of Ep=320 in one tile: S is read once
-typedef Cfg<128, 64, 2, 2> CfgNarrowN;
-typedef Cfg<128, 128, 2, 2> CfgSquare;
-typedef Cfg<64, 64, 2, 2> CfgSmall;
-typedef Cfg<64, 64, 4, 1> CfgStepSmall; // LSTM step, small batch: 16 rows x one 64-col gate block per wave
+typedef Cfg<128, 320, 2, 4, 2> CfgWideN;   // 512 threads; all of Ep=320 in one tile: S is read once
+typedef Cfg<128, 64, 2, 2, 2> CfgNarrowN;
+typedef Cfg<128, 128, 2, 2, 2> CfgSquare;
+typedef Cfg<64, 64, 2, 2, 2> CfgSmall;
+// LSTM steps are small latency-bound GEMMs: 4 K-tiles of loads in flight per workgroup.
+typedef Cfg<128, 128, 4, 2, 4> CfgStepBig;   // 512 threads: 32 rows x one 64-col gate block per wave
+typedef Cfg<64, 64, 4, 1, 4> CfgStepSmall;   // small batch: 16 rows x one gate block per wave
+typedef Cfg<64, 64, 4, 2, 4> CfgStepBwd;     // 512 threads: 16 rows x 32 units per wave
 
 template <class C, int KIND>
 void launch_softemb_fwd(const Shape& s, const void* src, long long sT, long long sB, const unsigned char* need,
@@ -164,12 +168,24 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
     const bf16raw* wemb = at<bf16raw>(packed, pl.wemb);
     const bf16raw* DX = at<bf16raw>(ws, wl.off[SAD_WS_DX]);
+    // A-stationary fast path for the shipped embedding size (E = 300 -> Ep = 320 = 32*10)
+    const bool rs = s.Ep == 320;
+    const int mtiles = ceil_div(s.M, 256), ntiles = s.Vp / 64;
+    int vsplit = 1024 / mtiles;                       // ~4 workgroups per CU for dynamic balance
+    vsplit = vsplit < 1 ? 1 : (vsplit > ntiles ? ntiles : vsplit);
+    const int nt_per = ceil_div(ntiles, vsplit);
+    const dim3 rs_grid(mtiles, ceil_div(ntiles, nt_per));
     if (kind == SAD_SRC_F32) {
         if (check_aligned(dsrc, 4, "dsrc")) return -1;
-        launch_softemb_bwd<CfgSquare, SRC_F32>(s, DX, need, wemb, dsrc, sT, sB, st);
+        if (rs) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_F32>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
+        else launch_softemb_bwd<CfgSquare, SRC_F32>(s, DX, need, wemb, dsrc, sT, sB, st);
     } else if (kind == SAD_SRC_BF16) {
         if (check_aligned(dsrc, 2, "dsrc")) return -1;
-        launch_softemb_bwd<CfgSquare, SRC_BF16>(s, DX, need, wemb, dsrc, sT, sB, st);
+        static const int kdbg = getenv("SAD_DBG_K1B") ? atoi(getenv("SAD_DBG_K1B")) : 0;   // timing diagnostics only
+#define SAD_RS(D) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_BF16, D>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per)
+        if (rs) { switch (kdbg) { case 1: SAD_RS(1); break; case 2: SAD_RS(2); break; case 3: SAD_RS(3); break; case 4: SAD_RS(4); break; case 5: SAD_RS(5); break; case 6: SAD_RS(6); break; default: SAD_RS(0); } }
+#undef SAD_RS
+        else launch_softemb_bwd<CfgSquare, SRC_BF16>(s, DX, need, wemb, dsrc, sT, sB, st);
     } else {
         return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
     }
@@ -367,15 +383,16 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
     }
 
     // K2b: T dependent steps, both directions per launch
+    static const int dbg = getenv("SAD_DBG") ? atoi(getenv("SAD_DBG")) : 0;   // timing diagnostics only
     for (int step = 0; step < s.T; ++step) {
         if (s.B >= 512) {
-            typedef CfgSquare C;
+            typedef CfgStepBig C;
             dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
-            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs);
+            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, dbg);
         } else {
             typedef CfgStepSmall C;
             dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
-            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs);
+            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, dbg);
         }
     }
     SAD_CHECK_LAUNCH("k_lstm_fwd");
@@ -464,7 +481,7 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     }
     // K2': BPTT
     for (int step = 0; step < s.T; ++step) {
-        typedef CfgSmall C;
+        typedef CfgStepBwd C;
         dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
         hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whhT), G, Cs,
                            DHFIN, DC, DZ);

@@ -134,16 +134,23 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[C::TM][C::TN]) {
 }
 
 // Aligned 16-byte load of 8 bf16 from a packed (padded, 16-B aligned) matrix; zero outside
-// [rows) x [K).  Branch-free on purpose (clamped address + select): see the steady-state note above.
+// [rows) x [K).  Two forms, chosen per kernel by measurement (profiles/r01_ab_loaders.txt): the
+// predicated form is faster everywhere except the store-heavy in-projection, where the
+// branch-free one (clamped address + select) lets hipcc keep counted vmcnt waits.
 __device__ __forceinline__ u32x4 load_packed(const bf16raw* base, long long ld, int row, int rows, int k, int K) {
+    if (row < rows && k < K) return *(const u32x4*)(base + (long long)row * ld + k);
+    return u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ u32x4 load_packed_nb(const bf16raw* base, long long ld, int row, int rows, int k, int K) {
     const bool ok = row < rows && k < K;
     const u32x4 v = *(const u32x4*)(base + (ok ? (long long)row * ld + k : 0ll));
     return ok ? v : u32x4{0u, 0u, 0u, 0u};
 }
-// Same for a row pointer that may be invalid (`ok` false): `dummy` must be readable for 16 bytes.
+// Row pointer that may be invalid (`ok` false).
 __device__ __forceinline__ u32x4 load_row(const bf16raw* row, bool ok, const bf16raw* dummy, int k) {
-    const u32x4 v = *(const u32x4*)(ok ? row + k : dummy);
-    return ok ? v : u32x4{0u, 0u, 0u, 0u};
+    (void)dummy;
+    if (ok) return *(const u32x4*)(row + k);
+    return u32x4{0u, 0u, 0u, 0u};
 }
 
 struct Ident {

@@ -189,8 +189,8 @@ __global__ __launch_bounds__(C::NT) void k_inproj_fwd(Shape s, const bf16raw* __
     zero_acc<C>(acc);
     const int Ep = s.Ep, M = s.M, Ncat = s.Ncat;
     gemm_core<C, u32x4>(
-        Ep, [&](int, int r, int k) { return load_packed(X, Ep, m0 + r, M, k, Ep); }, Ident(),
-        [&](int, int r, int k) { return load_packed(wcat, Ep, n0 + r, Ncat, k, Ep); }, acc, As, Bs);
+        Ep, [&](int, int r, int k) { return load_packed_nb(X, Ep, m0 + r, M, k, Ep); }, Ident(),
+        [&](int, int r, int k) { return load_packed_nb(wcat, Ep, n0 + r, Ncat, k, Ep); }, acc, As, Bs);
     const int wm = wave / C::WN, wn = wave % C::WN, G2 = 2 * s.Gp;
 #pragma unroll
     for (int tm = 0; tm < C::TM; ++tm) {

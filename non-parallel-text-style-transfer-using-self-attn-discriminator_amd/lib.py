@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_native", "libsad.so")
+LIB_PATH = os.environ.get("SAD_LIB") or os.path.join(_HERE, "_native", "libsad.so")   # SAD_LIB: A/B builds
 
 SRC_IDS, SRC_F32, SRC_BF16 = 0, 1, 2
 

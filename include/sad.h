@@ -113,6 +113,7 @@ enum sad_ws_field {
     SAD_WS_DQ,       /* fp32 [B][Hp] */
     SAD_WS_DHFIN,    /* fp32 [B][2][Hp] */
     SAD_WS_DC,       /* fp32 [B][2][Hp] */
+    SAD_WS_ACCF,     /* fp32 [T*B][Ep] split-K accumulator (small batches) */
     SAD_WS_NFIELDS
 };
 

@@ -112,7 +112,8 @@ struct SoftRow<SRC_BF16> {
 template <class C, int KIND>
 __global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __restrict__ src, long long sT, long long sB,
                                                       const unsigned char* __restrict__ need,
-                                                      const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X) {
+                                                      const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X,
+                                                      float* __restrict__ accf, int ksplit) {
     __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
     __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
     typedef SoftRow<KIND> SR;
@@ -133,13 +134,18 @@ __global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __re
             }
         }
         const int V = s.V, Vp = s.Vp, Ep = s.Ep;
+        // split-K (small batches: few row tiles, K = V is long): blockIdx.z owns whole K-tiles
+        const int tps = ceil_div(ceil_div(V, C::BK), ksplit);
+        const int k0 = blockIdx.z * tps * C::BK;
+        const int k1 = k0 + tps * C::BK < V ? k0 + tps * C::BK : V;
         const int Vmain = V / C::BK * C::BK;     // whole K-tiles: unguarded, branch-free loads
+        const int kme = k1 < Vmain ? k1 : Vmain; // end of this split's whole tiles
         const Elem* dummy = (const Elem*)src;
-        if (Vmain > 0)
+        if (kme > k0)
             gemm_core<C, typename SR::Raw>(
-                Vmain, [&](int i, int, int k) { return SR::load_fast(arow[i], dummy, k); }, typename SR::Cvt(),
-                [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, k, Vp); }, acc, As, Bs);
-        if (Vmain < V)                           // ragged last tile (V is odd): element-guarded loads
+                kme - k0, [&](int i, int, int k) { return SR::load_fast(arow[i], dummy, k0 + k); }, typename SR::Cvt(),
+                [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, k0 + k, Vp); }, acc, As, Bs);
+        if (k1 > Vmain && k1 > k0)               // ragged last tile (V is odd): element-guarded loads
             gemm_core<C, typename SR::Raw>(
                 V - Vmain, [&](int i, int, int k) { return SR::load(arow[i], Vmain + k, V); }, typename SR::Cvt(),
                 [&](int, int r, int k) { return load_packed(wembT, Vp, n0 + r, Ep, Vmain + k, Vp); }, acc, As, Bs);
@@ -151,8 +157,23 @@ __global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __re
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) {
             const int n = n0 + frag_col<C>(wn, tn, lane);
-            if (m < s.M && n < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
+            if (m < s.M && n < s.Ep) {
+                if (ksplit > 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(&accf[(long long)m * s.Ep + n + e], acc[tm][tn][e]);
+                } else {
+                    *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
+                }
+            }
         }
+    }
+}
+
+// fp32 split-K accumulator -> bf16 operand buffer (8 elements per thread)
+__global__ void k_cvt_bf16(const float* __restrict__ src, bf16raw* __restrict__ dst, long long n8) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
+        *(u32x4*)(dst + i * 8) = pack_bf16x8(a, b);
     }
 }
 
@@ -692,7 +713,8 @@ __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int
 template <class C>
 __global__ __launch_bounds__(C::NT) void k_inproj_bwd(Shape s, const bf16raw* __restrict__ DZ,
                                                      const unsigned char* __restrict__ need,
-                                                     const bf16raw* __restrict__ wcatT, bf16raw* __restrict__ DX) {
+                                                     const bf16raw* __restrict__ wcatT, bf16raw* __restrict__ DX,
+                                                     float* __restrict__ accf, int ksplit) {
     __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
     __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
     const int m0 = blockIdx.x * C::BM, n0 = blockIdx.y * C::BN;
@@ -701,9 +723,13 @@ __global__ __launch_bounds__(C::NT) void k_inproj_bwd(Shape s, const bf16raw* __
     zero_acc<C>(acc);
     const int Ep = s.Ep, M = s.M, Ncat = s.Ncat;
     if (tile_any_need<C>(need, m0, M)) {
-        gemm_core<C, u32x4>(
-            Ncat, [&](int, int r, int k) { return load_packed(DZ, Ncat, m0 + r, M, k, Ncat); }, Ident(),
-            [&](int, int r, int k) { return load_packed(wcatT, Ncat, n0 + r, Ep, k, Ncat); }, acc, As, Bs);
+        const int tps = ceil_div(ceil_div(Ncat, C::BK), ksplit);
+        const int k0 = blockIdx.z * tps * C::BK;
+        const int k1 = k0 + tps * C::BK < Ncat ? k0 + tps * C::BK : Ncat;
+        if (k1 > k0)
+            gemm_core<C, u32x4>(
+                k1 - k0, [&](int, int r, int k) { return load_packed(DZ, Ncat, m0 + r, M, k0 + k, Ncat); }, Ident(),
+                [&](int, int r, int k) { return load_packed(wcatT, Ncat, n0 + r, Ep, k0 + k, Ncat); }, acc, As, Bs);
     }
     const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
@@ -712,7 +738,14 @@ __global__ __launch_bounds__(C::NT) void k_inproj_bwd(Shape s, const bf16raw* __
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) {
             const int n = n0 + frag_col<C>(wn, tn, lane);
-            if (m < M && n < Ep) *(u32x2*)&DX[(long long)m * Ep + n] = pack_bf16x4(acc[tm][tn]);
+            if (m < M && n < Ep) {
+                if (ksplit > 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(&accf[(long long)m * Ep + n + e], acc[tm][tn][e]);
+                } else {
+                    *(u32x2*)&DX[(long long)m * Ep + n] = pack_bf16x4(acc[tm][tn]);
+                }
+            }
         }
     }
 }

@@ -84,6 +84,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_DQ] = B * s.Hp * 4;
     w.bytes[SAD_WS_DHFIN] = B * 2 * s.Hp * 4;
     w.bytes[SAD_WS_DC] = B * 2 * s.Hp * 4;
+    w.bytes[SAD_WS_ACCF] = M * s.Ep * 4;
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -129,11 +130,32 @@ typedef Cfg<128, 128, 4, 2, 4> CfgStepBig;   // 512 threads: 32 rows x one 64-co
 typedef Cfg<64, 64, 4, 1, 4> CfgStepSmall;   // small batch: 16 rows x one gate block per wave
 typedef Cfg<64, 64, 4, 2, 4> CfgStepBwd;     // 512 threads: 16 rows x 32 units per wave
 
+// Split-K factor for GEMMs with few output tiles and a long K (small batches): aim at ~1 workgroup
+// per CU, keep >= 2 K-tiles per split.  Partial sums meet in an fp32 buffer via atomics.
+int split_k(int tiles, int ktiles) {
+    if (tiles >= 128 || ktiles < 4) return 1;
+    int ks = 256 / tiles;
+    if (ks > ktiles / 2) ks = ktiles / 2;
+    if (ks > 64) ks = 64;
+    return ks < 1 ? 1 : ks;
+}
+void launch_cvt(const float* src, bf16raw* dst, long long n, hipStream_t st) {
+    const long long n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_cvt_bf16, dim3(blocks), dim3(256), 0, st, src, dst, n8);
+}
+
 template <class C, int KIND>
 void launch_softemb_fwd(const Shape& s, const void* src, long long sT, long long sB, const unsigned char* need,
-                        const bf16raw* wembT, bf16raw* X, hipStream_t st) {
-    dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN));
-    hipLaunchKernelGGL((k_softemb_fwd<C, KIND>), grid, dim3(C::NT), 0, st, s, src, sT, sB, need, wembT, X);
+                        const bf16raw* wembT, bf16raw* X, float* accf, hipStream_t st) {
+    const int tiles = ceil_div(s.M, C::BM) * ceil_div(s.Ep, C::BN);
+    const int ksplit = split_k(tiles, ceil_div(s.V, C::BK));
+    dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN), ksplit);
+    if (ksplit > 1) (void)hipMemsetAsync(accf, 0, (size_t)s.M * s.Ep * 4, st);
+    hipLaunchKernelGGL((k_softemb_fwd<C, KIND>), grid, dim3(C::NT), 0, st, s, src, sT, sB, need, wembT, X, accf, ksplit);
+    if (ksplit > 1) launch_cvt(accf, X, (long long)s.M * s.Ep, st);
 }
 template <class C, int KIND>
 void launch_softemb_bwd(const Shape& s, const bf16raw* DX, const unsigned char* need, const bf16raw* wemb, void* dS,
@@ -147,15 +169,16 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
     const bf16raw* wembT = at<bf16raw>(packed, pl.wembT);
     bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
+    float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
     const bool wide = s.Ep > 128;
     if (kind == SAD_SRC_F32) {
         if (check_aligned(src, 4, "src")) return -1;
-        if (wide) launch_softemb_fwd<CfgWideN, SRC_F32>(s, src, sT, sB, need, wembT, X, st);
-        else launch_softemb_fwd<CfgNarrowN, SRC_F32>(s, src, sT, sB, need, wembT, X, st);
+        if (wide) launch_softemb_fwd<CfgWideN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
+        else launch_softemb_fwd<CfgNarrowN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
     } else if (kind == SAD_SRC_BF16) {
         if (check_aligned(src, 2, "src")) return -1;
-        if (wide) launch_softemb_fwd<CfgWideN, SRC_BF16>(s, src, sT, sB, need, wembT, X, st);
-        else launch_softemb_fwd<CfgNarrowN, SRC_BF16>(s, src, sT, sB, need, wembT, X, st);
+        if (wide) launch_softemb_fwd<CfgWideN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
+        else launch_softemb_fwd<CfgNarrowN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
     } else {
         return fail(-1, "soft-embedding stage needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
     }
@@ -488,14 +511,20 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     }
     SAD_CHECK_LAUNCH("k_lstm_bwd");
     // K2a' + K3'
-    if (s.Ep > 128) {
-        typedef CfgWideN C;
-        dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN));
-        hipLaunchKernelGGL((k_inproj_bwd<C>), grid, dim3(C::NT), 0, st, s, DZ, need, at<bf16raw>(packed, pl.wcatT), DX);
-    } else {
-        typedef CfgNarrowN C;
-        dim3 grid(ceil_div(s.M, C::BM), ceil_div(s.Ep, C::BN));
-        hipLaunchKernelGGL((k_inproj_bwd<C>), grid, dim3(C::NT), 0, st, s, DZ, need, at<bf16raw>(packed, pl.wcatT), DX);
+    {
+        float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
+        const bool wide = s.Ep > 128;
+        const int bm = 128, bn = wide ? 320 : 64;
+        const int ksplit = split_k(ceil_div(s.M, bm) * ceil_div(s.Ep, bn), ceil_div(s.Ncat, 64));
+        dim3 grid(ceil_div(s.M, bm), ceil_div(s.Ep, bn), ksplit);
+        if (ksplit > 1) (void)hipMemsetAsync(accf, 0, (size_t)s.M * s.Ep * 4, st);
+        if (wide)
+            hipLaunchKernelGGL((k_inproj_bwd<CfgWideN>), grid, dim3(CfgWideN::NT), 0, st, s, DZ, need,
+                               at<bf16raw>(packed, pl.wcatT), DX, accf, ksplit);
+        else
+            hipLaunchKernelGGL((k_inproj_bwd<CfgNarrowN>), grid, dim3(CfgNarrowN::NT), 0, st, s, DZ, need,
+                               at<bf16raw>(packed, pl.wcatT), DX, accf, ksplit);
+        if (ksplit > 1) launch_cvt(accf, DX, (long long)s.M * s.Ep, st);
     }
     SAD_CHECK_LAUNCH("k_inproj_bwd");
     // K1'

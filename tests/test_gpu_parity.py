@@ -201,9 +201,11 @@ def test_cfg3_subsample_vs_oracle_and_shard_invariance():
       * 12 sentences spread over the batch are checked against the oracle run on just those
         sentences (sentences are independent, SURVEY.md §8 e1);
       * size-independent properties: attention weights sum to 1 and vanish under the mask, dS rows
-        are exactly zero for t >= len, scaling dloss by 2 scales dS by exactly 2 (linearity,
-        bit-exact), and scoring the two halves of the batch separately (what 2-GPU data
-        parallelism does) reproduces the full-batch result bit for bit."""
+        are exactly zero for t >= len, dS is linear in dloss, and scoring the two halves of the
+        batch separately (what 2-GPU data parallelism does) reproduces the full-batch result.
+    At this batch the K1 / in-projection-backward GEMMs run split-K with fp32 atomics (few row
+    tiles), whose summation order is not fixed, so the last two properties are checked to 2e-3 (fp32 outputs) /
+    1e-2 (bf16 dS, one ulp = 4e-3) here and BIT-EXACTLY at the bench batch in test_full_batch_bit_exact_properties."""
     B, T, V, E, H = 256, 32, 9353, 300, 512
     params = synth.make_params(V, E, H, seed=21)
     lengths, S, mask, labels = _cfg3_inputs(B)
@@ -221,14 +223,55 @@ def test_cfg3_subsample_vs_oracle_and_shard_invariance():
     for bi, ln in enumerate(lengths):
         assert np.all(full["dS"][bi, ln:] == 0)
     twice = run_sad(params, S, lengths, mask, labels, s_dtype="bf16", dloss=np.full((B,), 2.0 / B))
-    assert np.array_equal(twice["dS"], 2.0 * full["dS"])
+    assert relerr(twice["dS"], 2.0 * full["dS"]) < 1e-2
     h = B // 2
     for lo, hi in ((0, h), (h, B)):
         part = run_sad(params, S[lo:hi], lengths[lo:hi], mask[lo:hi], labels[lo:hi], s_dtype="bf16",
                        dloss=np.full((hi - lo,), 1.0 / B))
-        assert np.array_equal(part["logits"], full["logits"][lo:hi])
-        assert np.array_equal(part["weights"], full["weights"][lo:hi])
-        assert np.array_equal(part["dS"], full["dS"][lo:hi])
+        assert relerr(part["logits"], full["logits"][lo:hi]) < 2e-3
+        assert relerr(part["weights"], full["weights"][lo:hi]) < 2e-3
+        assert relerr(part["dS"], full["dS"][lo:hi]) < 1e-2      # dS is stored in bf16: one ulp = 4e-3
+
+
+def test_full_batch_bit_exact_properties():
+    """BASELINE config-3 at its FULL size (B=1024, T=32, V=9353, bf16 one-hot soft tokens built on
+    the device): properties that need no oracle, checked bit for bit —
+      * data parallelism: the two half batches scored separately == the full batch (logits,
+        attention weights, dS), which is the N-rank == 1-rank invariant of the weak-scaling bench;
+      * linearity: dloss * 2 gives exactly 2 * dS;
+      * dS is exactly zero for t >= len and exactly reproducible run to run."""
+    import torch
+    from sad_amd import functional as Fn
+    B, T, V, E, H = 1024, 32, 9353, 300, 512
+    dev = torch.device("cuda:0")
+    params = synth.make_params(V, E, H, seed=21)
+    pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})
+    lengths = synth.make_lengths(B, T, seed=77)
+    ids = torch.from_numpy(synth.make_token_ids(B, T, V, lengths, seed=77)).to(dev)
+    S_store = torch.zeros((T, B, V), dtype=torch.bfloat16, device=dev)       # time-major storage
+    S_store.scatter_(2, ids.t().unsqueeze(2), 1.0)
+    labels = torch.from_numpy(synth.make_labels(B, seed=77)).to(dev)
+    mask0 = torch.from_numpy(synth.transfer_mask(lengths, T)).to(dev)
+    ln = torch.from_numpy(lengths)
+
+    def run(lo, hi, scale):
+        S = S_store[:, lo:hi].transpose(0, 1).detach().requires_grad_(True)   # strided [b,T,V] view
+        loss, logits, w = Fn.discriminator_loss(S, ln[lo:hi], mask0[lo:hi].clone(), labels[lo:hi], pw)
+        (loss.sum() * (scale / B)).backward()
+        return logits.detach(), w.detach(), S.grad
+
+    lg, w, dS = run(0, B, 1.0)
+    lg2, w2, dS2 = run(0, B, 1.0)
+    assert torch.equal(lg, lg2) and torch.equal(dS, dS2)                      # reproducible
+    _, _, dS_twice = run(0, B, 2.0)
+    assert torch.equal(dS_twice.float(), 2.0 * dS.float())                    # linear, bit-exact
+    pad = torch.arange(T, device=dev)[None, :] >= ln.to(dev)[:, None]
+    assert bool((dS[pad] == 0).all())
+    assert bool((dS[~pad].float().abs().sum() > 0))
+    h = B // 2
+    for lo, hi in ((0, h), (h, B)):
+        plg, pw_, pdS = run(lo, hi, 1.0)
+        assert torch.equal(plg, lg[lo:hi]) and torch.equal(pw_, w[lo:hi]) and torch.equal(pdS, dS[lo:hi])
 
 
 def test_ragged_and_edge_shapes():

@@ -188,6 +188,15 @@ def main():
                                    avg_launch_us=round((k_fwd if dom is k_bwd else k_bwd)["seconds"] * 1e6, 1),
                                    GBps=round((k_fwd if dom is k_bwd else k_bwd)["GBps"], 1),
                                    mfma_TFLOPs=round((k_fwd if dom is k_bwd else k_bwd)["TFLOPs"], 1)))
+        # HBM traffic of the dominant kernel from the committed PMC passes of THIS command
+        # (tools/pmc_bench.sh -> profiles/pmc_bench_traffic.json; FETCH_SIZE doubled per the gfx950 note)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_bench_traffic.json")))
+            key = [k for k in pmc if k.startswith("k_softemb_bwd" if dom is k_bwd else "k_softemb_fwd")]
+            if key and a.workload == "cfg3" and w["s_dtype"] == "bf16":
+                roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))

@@ -100,7 +100,7 @@ enum sad_ws_field {
     SAD_WS_LENS = 0, /* int32 [B] clamped lengths */
     SAD_WS_NEED,     /* u8   [T*B] */
     SAD_WS_X,        /* bf16 [T*B][Ep] */
-    SAD_WS_G,        /* fp32 [T*B][2][Gp] activated gates, permuted columns */
+    SAD_WS_G,        /* fp32 [T*B][2*Gp+64] activated gates [fwd | rev | pad], permuted columns */
     SAD_WS_CS,       /* fp32 [T*B][2][Hp] */
     SAD_WS_HS,       /* bf16 [T*B][2][Hp] */
     SAD_WS_KK,       /* fp32 [T*B][Hp] */

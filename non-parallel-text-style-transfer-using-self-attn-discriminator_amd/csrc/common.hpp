@@ -28,6 +28,8 @@ struct Shape {
     int Vp;    // V rounded up to 64   (K of the soft-embedding GEMM, rows of the packed embedding)
     int Ncat;  // 2*Gp + Hp            (fused in-projection columns: fwd gates | rev gates | attention keys)
     int M;     // T*B token rows
+    int Gld;   // row pitch of G in floats: 2*Gp + 64 (breaks the power-of-two 16 KB pitch: 16-row store
+               // instructions at a 2^k pitch camp on one HBM channel)
 };
 
 __host__ __device__ inline Shape make_shape(int B, int T, int V, int E, int H, int L) {
@@ -39,6 +41,7 @@ __host__ __device__ inline Shape make_shape(int B, int T, int V, int E, int H, i
     s.Vp = ceil_to(V, 64);
     s.Ncat = 2 * s.Gp + s.Hp;
     s.M = T * B;
+    s.Gld = 2 * s.Gp + 64;
     return s;
 }
 

@@ -4,7 +4,8 @@
 // Buffers (all time-major, token row m = t*B + b; see DESIGN.md "Data layout in HBM"):
 //   need [M]           u8    bit0: t < len[b] (LSTM-active), bit1: !mask'[b,t] (attention-active)
 //   X    [M][Ep]       bf16  embedded tokens
-//   G    [M][2][Gp]    fp32  gate pre-activations (input part) -> overwritten by activated i,f,g,o
+//   G    [M][Gld]      fp32  [fwd Gp | rev Gp | 64 pad]: gate pre-activations (input part) -> overwritten by
+//                            activated i,f,g,o
 //   Cs   [M][2][Hp]    fp32  cell state after step t
 //   Hs   [M][2][Hp]    bf16  hidden state after step t (MFMA operand of the next step)
 //   Kk   [M][Hp]       fp32  attention keys/values  linear_emb(X)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(C::NT) void k_inproj_fwd(Shape s, const bf16raw* __
             if (m < M && n < Ncat) {
                 const f32x4 v = acc[tm][tn] + *(const f32x4*)&bcat[n];
                 if (n < G2)
-                    *(f32x4*)&G[(long long)m * G2 + n] = v;
+                    *(f32x4*)&G[(long long)m * s.Gld + n] = v;
                 else
                     *(f32x4*)&Kk[(long long)m * s.Hp + (n - G2)] = v;
             }
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (act[tm] && !(dbg & 4)) {
-            const float* g = G + (((long long)t * B + b) * 2 + dir) * Gp + col0 + u4;
+            const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + col0 + u4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) pre[tm][q] = *(const f32x4*)(g + 16 * q);
             if (tp_ok && lens[b] > tp) cp[tm] = *(const f32x4*)&Cs[(((long long)tp * B + b) * 2 + dir) * Hp + j];
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
         if (!act[tm]) continue;
         const int b = b0 + frag_row<C>(wm, tm, lane);
         const long long row = ((long long)t * B + b) * 2 + dir;
-        float* g = G + row * Gp + col0 + u4;
+        float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + col0 + u4;
         const f32x4 pi = acc[tm][0] + pre[tm][0];
         const f32x4 pf = acc[tm][1] + pre[tm][1];
         const f32x4 pg = acc[tm][2] + pre[tm][2];
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int
             const int j = n0 + frag_col<C>(wn, tnn, lane);   // 4 consecutive hidden units
             if (!act[tm] || j >= Hp) continue;
             const int pc = (j >> 4) * 64 + (j & 15);         // permuted column of gate 0
-            const float* g = G + row * Gp + pc;
+            const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + pc;
             p.gi = *(const f32x4*)(g + 0);
             p.gf = *(const f32x4*)(g + 16);
             p.gg = *(const f32x4*)(g + 32);
@@ -805,36 +806,139 @@ __global__ __launch_bounds__(C::NT) void k_softemb_bwd(Shape s, const bf16raw* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1' fast path (Ep == 32*KS): A-stationary.  A workgroup owns 256 token rows x a range of
-// 64-column vocabulary tiles.  Each of its 8 waves keeps the dX fragments of its 32 rows for the
-// WHOLE K = Ep in registers (loaded once), the embedding tile [64][Ep] (one contiguous 64*Ep*2-byte
-// block of the packed table) is staged through LDS and shared by all 8 waves, so per output byte
-// the kernel moves ~Ep/256 bytes of operands instead of re-reading both operands per 128x128 tile.
+// A-stationary GEMM for K = Ep = 32*KS (the embedding size): used by K1' (dS = dX . W_emb^T) and by
+// the fused in-projection (G|Kk = X . Wcat^T).  A workgroup owns 256 token rows x a range of
+// 64-column tiles of Bt.  Each of its 8 waves keeps the A fragments of its 32 rows for the WHOLE K
+// in registers (loaded once); the Bt tile [64][Ep] (one contiguous 64*Ep*2-byte block of the packed
+// matrix) is staged through LDS and shared by all 8 waves, so per output byte the kernel moves
+// ~Ep/256 bytes of operands instead of re-reading both operands per 128x128 tile.
 //   * LDS image: unpadded rows, 16-byte chunks XOR-swizzled with (row>>1)&7 -> conflict-free
 //     ds_read_b128 fragment reads (MI355X bank rule: 64 banks, 16-lane groups).
-//   * LDS row rho holds vocabulary column sigma(rho) (a bit permutation), so that a lane's
-//     accumulator tile pairs are 8 CONSECUTIVE vocabulary entries: 16-/32-byte stores per lane,
-//     64/128 contiguous bytes per token row per store instruction.
+//   * PAIR (2-byte outputs): LDS row rho holds Bt row sigma(rho) (a bit permutation), so that a
+//     lane's accumulator tile pairs are 8 CONSECUTIVE output columns -> one 16-byte store per lane.
+//     Either way every store instruction writes 64 CONTIGUOUS bytes per token row.
+//   * Pipeline per tile (ONE LDS buffer): compute(nt) | barrier | LDS <- tile nt+1 | barrier |
+//     stores(nt) | issue loads(nt+2).  vmcnt retires in order, so the wait in front of the LDS write
+//     also covers the stores of tile nt-1, which by then had a whole MFMA phase to drain.
+// PAIR: epi(tm, n, lo, hi) = columns [n, n+8) of this lane's row tm; else epi(tm, n, v) = [n, n+4).
 // ------------------------------------------------------------------------------------------------
-template <int KS, int KIND, int DBG = 0>
+template <int KS, bool PAIR, class Epi>
+__device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, const int (&mrow)[2], bool wave_any,
+                                        int block_any, const bf16raw* __restrict__ Bt, int nt0, int nt1,
+                                        unsigned char* Bs, Epi epi) {
+    constexpr int EP = KS * 32, BN = 64, NTH = 512;
+    constexpr int ROWB = EP * 2;              // bytes per Bt row
+    constexpr int CPR = EP / 8;               // 16-byte chunks per row
+    constexpr int SCH = BN * CPR / NTH;       // staging chunks per thread
+    static_assert((BN * CPR) % NTH == 0, "tile must split evenly over the workgroup");
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(A + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
+            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    // Retire the fragment loads HERE.  Otherwise they are still "pending" at the loop header and
+    // hipcc's waitcnt pass, merging that state over the back edge, puts s_waitcnt vmcnt(0) in front
+    // of the first MFMA of EVERY tile — draining the previous tile's stores and the prefetch.
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(a[tm][ks]));
+
+    // staging map of this thread: global chunk g -> (Bt row vloc, chunk) -> swizzled LDS offset
+    int soff[SCH], goff[SCH];
+#pragma unroll
+    for (int i = 0; i < SCH; ++i) {
+        const int g = tid + i * NTH;
+        const int vloc = g / CPR, ch = g - vloc * CPR;
+        // PAIR: vloc = 32p + 8g + 4tau + r  <->  rho = 32p + 16tau + 4g + r ; else identity
+        const int rho = PAIR ? (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3) : vloc;
+        soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
+        goff[i] = g * 8;                    // elements from the tile's first row (tile is contiguous)
+    }
+    u32x4 st[SCH];
+    auto load_tile = [&](int nt) {
+        const bf16raw* base = Bt + (long long)nt * BN * EP;
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
+    };
+    // fragment read offsets: LDS row rho = tn*16 + (lane&15), chunk = ks*4 + (lane>>4)
+    int roff[4], rsw[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int rho = tn * 16 + (lane & 15);
+        roff[tn] = rho * ROWB;
+        rsw[tn] = (rho >> 1) & 7;
+    }
+    if (block_any) {
+        load_tile(nt0);
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
+        __syncthreads();
+        if (nt0 + 1 < nt1) load_tile(nt0 + 1);
+    }
+    for (int nt = nt0; nt < nt1; ++nt) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (block_any) {
+            if (wave_any) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 bfr[4];
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        bfr[tn] = *(const bf16x8*)&Bs[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+                }
+            }
+            __syncthreads();                       // all waves finished reading tile nt
+            if (nt + 1 < nt1) {
+#pragma unroll
+                for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    epi(tm, nt * BN + 32 * pr + 8 * (lane >> 4), acc[tm][2 * pr], acc[tm][2 * pr + 1]);
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) epi(tm, nt * BN + 16 * tn + 4 * (lane >> 4), acc[tm][tn]);
+            }
+        }
+        if (block_any && nt + 2 < nt1) load_tile(nt + 2);
+    }
+}
+
+// K1' fast path: dS[m][v] = sum_e dX[m][e] * W_emb[v][e], every (m, v) written in the caller's
+// dtype/strides (rows with t >= len come out as exact zeros because their dX rows are zero).
+template <int KS, int KIND>
 __global__ __launch_bounds__(512) void k_softemb_bwd_rs(Shape s, const bf16raw* __restrict__ DX,
                                                        const unsigned char* __restrict__ need,
                                                        const bf16raw* __restrict__ wemb, void* __restrict__ dS,
                                                        long long sT, long long sB, int nt_per) {
-    constexpr int EP = KS * 32, BN = 64, BM = 256, NTH = 512;
-    constexpr int ROWB = EP * 2;              // bytes per embedding row
-    constexpr int CPR = EP / 8;               // 16-byte chunks per row
-    constexpr int SCH = BN * CPR / NTH;       // staging chunks per thread
-    static_assert((BN * CPR) % NTH == 0, "tile must split evenly over the workgroup");
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROWB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM;
-    const int ntiles = s.Vp / BN;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * KS * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 256;
+    const int ntiles = s.Vp / 64;
     const int nt0 = blockIdx.y * nt_per;
     const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
     const int M = s.M, V = s.V;
-
-    // rows of this lane (two 16-row MFMA tiles of the wave's 32 rows) and their output bases
     int mrow[2];
     long long obase[2];
     int rneed = 0;
@@ -851,131 +955,66 @@ __global__ __launch_bounds__(512) void k_softemb_bwd_rs(Shape s, const bf16raw* 
     }
     const bool wave_any = __any(rneed != 0);
     const int block_any = __syncthreads_or(rneed != 0);
-
-    bf16x8 a[2][KS];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(DX + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
-            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
-        }
-
-    // Retire the fragment loads HERE.  Otherwise they are still "pending" at the loop header and
-    // hipcc's waitcnt pass, merging that state over the back edge, puts s_waitcnt vmcnt(0) in front
-    // of the first MFMA of EVERY tile — draining the previous tile's stores and the prefetch.
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(a[tm][ks]));
-
-    // staging map of this thread: global chunk g -> (vocabulary row vloc, chunk) -> swizzled LDS offset
-    int soff[SCH], goff[SCH];
-#pragma unroll
-    for (int i = 0; i < SCH; ++i) {
-        const int g = tid + i * NTH;
-        const int vloc = g / CPR, ch = g - vloc * CPR;
-        // vloc = 32p + 8g + 4tau + r  <->  rho = 32p + 16tau + 4g + r
-        const int rho = (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3);
-        soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
-        goff[i] = g * 8;                    // elements from the tile's first row (tile is contiguous)
-    }
-    u32x4 st[SCH];
-    auto load_tile = [&](int nt) {
-        const bf16raw* base = wemb + (long long)nt * BN * EP;
-#pragma unroll
-        for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
-    };
-    // fragment read offsets: LDS row rho = tn*16 + (lane&15), chunk = ks*4 + (lane>>4)
-    int roff[4], rsw[4];
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-        const int rho = tn * 16 + (lane & 15);
-        roff[tn] = rho * ROWB;
-        rsw[tn] = (rho >> 1) & 7;
-    }
-    // Pipeline per 64-column tile (ONE LDS buffer):  compute(nt) | barrier | LDS <- tile nt+1 |
-    // barrier | stores(nt) | issue loads(nt+2).  vmcnt retires in order, so the wait in front of the
-    // LDS write also covers the stores of tile nt-1 — which by then had a whole MFMA phase to
-    // drain; the stores of tile nt drain under compute(nt+1).  (Issuing the stores BEFORE the
-    // staging wait would expose the full HBM write latency on every tile.)
-    if (block_any) {
-        load_tile(nt0);
-#pragma unroll
-        for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
-        __syncthreads();
-        if (nt0 + 1 < nt1) load_tile(nt0 + 1);
-    }
-    for (int nt = nt0; nt < nt1; ++nt) {
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (block_any) {
-            if (wave_any && !(DBG & 2)) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 bfr[4];
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        bfr[tn] = *(const bf16x8*)&Bs[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
-#pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < 4; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+    if constexpr (KIND == SRC_F32) {
+        rs_gemm<KS, false>(DX, M, mrow, wave_any, block_any, wemb, nt0, nt1, Bs, [&](int tm, int n, f32x4 v) {
+            if (mrow[tm] >= M || n >= V) return;
+            float* p = (float*)dS + obase[tm] + n;
+            if (n + 4 <= V) {
+                *(f32x4u*)p = v;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < V) p[e] = v[e];
+            }
+        });
+    } else {
+        rs_gemm<KS, true>(DX, M, mrow, wave_any, block_any, wemb, nt0, nt1, Bs, [&](int tm, int n, f32x4 lo, f32x4 hi) {
+            if (mrow[tm] >= M || n >= V) return;
+            bf16raw* p = (bf16raw*)dS + obase[tm] + n;
+            if (n + 8 <= V) {
+                *(u32x4h*)p = pack_bf16x8(lo, hi);
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < V) p[e] = f32_to_bf16(lo[e]);
+                    if (n + 4 + e < V) p[4 + e] = f32_to_bf16(hi[e]);
                 }
             }
-            if (!(DBG & 4)) __syncthreads();                       // all waves finished reading tile nt
-            if (nt + 1 < nt1 && !(DBG & 4)) {
-#pragma unroll
-                for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
-            }
-            if (!(DBG & 4)) __syncthreads();
-        }
-        // lane owns columns [8g, 8g+8) (tiles 0,1) and [32+8g, 32+8g+8) (tiles 2,3) of the tile: each
-        // store instruction writes 64 contiguous bytes (bf16) / 2 x 64 (fp32) per token row.
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            if (DBG & 1) {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) asm volatile("" ::"v"(acc[tm][tn]));
-                continue;
-            }
-            if (mrow[tm] >= M) continue;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int n = nt * BN + 32 * pr + 8 * (lane >> 4);
-                if (n >= V) continue;
-                const f32x4 lo = acc[tm][2 * pr], hi = acc[tm][2 * pr + 1];
-                if constexpr (KIND == SRC_F32) {
-                    float* p = (float*)dS + obase[tm] + n;
-                    if (n + 8 <= V) {
-                        *(f32x4u*)p = lo;
-                        *(f32x4u*)(p + 4) = hi;
-                    } else {
-                        for (int e = 0; e < 4; ++e) {
-                            if (n + e < V) p[e] = lo[e];
-                            if (n + 4 + e < V) p[4 + e] = hi[e];
-                        }
-                    }
-                } else {
-                    bf16raw* p = (bf16raw*)dS + obase[tm] + n;
-                    if (n + 8 <= V) {
-                        *(u32x4h*)p = pack_bf16x8(lo, hi);
-                    } else {
-                        for (int e = 0; e < 4; ++e) {
-                            if (n + e < V) p[e] = f32_to_bf16(lo[e]);
-                            if (n + 4 + e < V) p[4 + e] = f32_to_bf16(hi[e]);
-                        }
-                    }
-                }
-            }
-        }
-        if (block_any && nt + 2 < nt1 && !(DBG & 4)) load_tile(nt + 2);
+        });
     }
+}
+
+// K2a + K3 fast path (Ep == 32*KS, Ncat % 64 == 0): [G | Kk][m] = X[m] . Wcat^T + bcat.
+// Rows nobody reads (need == 0) are not written.
+template <int KS>
+__global__ __launch_bounds__(512) void k_inproj_fwd_rs(Shape s, const bf16raw* __restrict__ X,
+                                                      const unsigned char* __restrict__ need,
+                                                      const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
+                                                      float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * KS * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 256;
+    const int ntiles = s.Ncat / 64;
+    const int nt0 = blockIdx.y * nt_per;
+    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
+    const int M = s.M, G2 = 2 * s.Gp;
+    int mrow[2];
+    bool rn[2];
+    int rneed = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = m0 + wave * 32 + tm * 16 + (lane & 15);
+        mrow[tm] = m;
+        rn[tm] = m < M && need[m] != 0;
+        rneed |= rn[tm] ? 1 : 0;
+    }
+    const bool wave_any = __any(rneed != 0);
+    const int block_any = __syncthreads_or(rneed != 0);
+    if (!block_any) return;
+    rs_gemm<KS, false>(X, M, mrow, wave_any, block_any, wcat, nt0, nt1, Bs, [&](int tm, int n, f32x4 v) {
+        if (!rn[tm]) return;
+        v += *(const f32x4*)&bcat[n];
+        float* p = n < G2 ? G + (long long)mrow[tm] * s.Gld + n : Kk + (long long)mrow[tm] * s.Hp + (n - G2);
+        *(f32x4*)p = v;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------

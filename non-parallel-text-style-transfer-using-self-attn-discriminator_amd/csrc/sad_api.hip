@@ -71,7 +71,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_LENS] = B * 4;
     w.bytes[SAD_WS_NEED] = M;
     w.bytes[SAD_WS_X] = M * s.Ep * 2;
-    w.bytes[SAD_WS_G] = M * 2 * s.Gp * 4;
+    w.bytes[SAD_WS_G] = M * s.Gld * 4;
     w.bytes[SAD_WS_CS] = M * 2 * s.Hp * 4;
     w.bytes[SAD_WS_HS] = M * 2 * s.Hp * 2;
     w.bytes[SAD_WS_KK] = M * s.Hp * 4;
@@ -204,10 +204,7 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
         else launch_softemb_bwd<CfgSquare, SRC_F32>(s, DX, need, wemb, dsrc, sT, sB, st);
     } else if (kind == SAD_SRC_BF16) {
         if (check_aligned(dsrc, 2, "dsrc")) return -1;
-        static const int kdbg = getenv("SAD_DBG_K1B") ? atoi(getenv("SAD_DBG_K1B")) : 0;   // timing diagnostics only
-#define SAD_RS(D) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_BF16, D>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per)
-        if (rs) { switch (kdbg) { case 1: SAD_RS(1); break; case 2: SAD_RS(2); break; case 3: SAD_RS(3); break; case 4: SAD_RS(4); break; case 5: SAD_RS(5); break; case 6: SAD_RS(6); break; default: SAD_RS(0); } }
-#undef SAD_RS
+        if (rs) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_BF16>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
         else launch_softemb_bwd<CfgSquare, SRC_BF16>(s, DX, need, wemb, dsrc, sT, sB, st);
     } else {
         return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
@@ -398,10 +395,19 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
 
     // K2a + K3
     {
-        typedef CfgSquare C;
-        dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
-        hipLaunchKernelGGL((k_inproj_fwd<C>), grid, dim3(C::NT), 0, st, s, X, need, at<bf16raw>(packed, pl.wcat),
-                           at<float>(packed, pl.bcat), G, Kk);
+        if (s.Ep == 320 && s.Ncat % 64 == 0) {          // A-stationary fast path (E = 300)
+            const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
+            int nsplit = 1024 / mtiles;
+            nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+            const int nt_per = ceil_div(ntiles, nsplit);
+            hipLaunchKernelGGL((k_inproj_fwd_rs<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(512), 0, st, s, X, need,
+                               at<bf16raw>(packed, pl.wcat), at<float>(packed, pl.bcat), G, Kk, nt_per);
+        } else {
+            typedef CfgSquare C;
+            dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
+            hipLaunchKernelGGL((k_inproj_fwd<C>), grid, dim3(C::NT), 0, st, s, X, need, at<bf16raw>(packed, pl.wcat),
+                               at<float>(packed, pl.bcat), G, Kk);
+        }
         SAD_CHECK_LAUNCH("k_inproj_fwd");
     }
 

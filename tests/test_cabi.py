@@ -39,7 +39,7 @@ def test_layout_and_padded_dims():
         end = off + nb
     assert end <= total
     M = 1024 * 32
-    assert lib.workspace_field(d, "G")[1] == M * 2 * 2048 * 4
+    assert lib.workspace_field(d, "G")[1] == M * (2 * 2048 + 64) * 4
     assert lib.workspace_field(d, "DZ")[1] == M * 4608 * 2
     # packed image: both orientations of the embedding dominate
     assert l.sad_packed_bytes(ctypes.byref(d)) > 2 * 9408 * 320 * 2

@@ -102,7 +102,7 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
             LENS=f("LENS", torch.int32).cpu().numpy(),
             NEED=f("NEED", torch.uint8).cpu().numpy().reshape(T, B),
             X=f("X", torch.bfloat16).float().cpu().numpy().reshape(T, B, Ep),
-            G=f("G", torch.float32).cpu().numpy().reshape(T, B, 2, Gp),
+            G=f("G", torch.float32).cpu().numpy().reshape(T, B, 2 * Gp + 64)[:, :, :2 * Gp].reshape(T, B, 2, Gp),
             CS=f("CS", torch.float32).cpu().numpy().reshape(T, B, 2, Hp),
             HS=f("HS", torch.bfloat16).float().cpu().numpy().reshape(T, B, 2, Hp),
             KK=f("KK", torch.float32).cpu().numpy().reshape(T, B, Hp),

@@ -1,0 +1,68 @@
+// Micro-benchmark (measurement tool, not product code): how fast can a [M][V] bf16 matrix with an
+// ODD row pitch (V = 9353 -> 18706-byte rows) be written / read with 16-byte accesses, as a function
+// of how a wavefront's 64 lanes are spread over rows?  RPW = rows per wave instruction; each row gets
+// 64/RPW lanes x 16 B contiguous.  A 512-thread workgroup owns 256 rows and walks the column range.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef unsigned u32x4h __attribute__((ext_vector_type(4), aligned(2)));
+typedef unsigned short u16;
+
+template <int RPW, bool STORE>
+__global__ __launch_bounds__(512) void k_rows(u16* __restrict__ p, int M, int V, long long pitch, int csplit, unsigned* sink) {
+    constexpr int LPR = 64 / RPW;            // lanes per row
+    constexpr int CW = LPR * 8;              // columns per wave instruction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 256 + wave * 32;       // this wave's 32 rows
+    const int cper = (V + csplit - 1) / csplit;
+    const int c0 = blockIdx.y * cper, c1 = min(V, c0 + cper);
+    const int r = lane / LPR, cl = (lane % LPR) * 8;
+    unsigned acc = 0;
+    for (int c = c0; c < c1; c += CW) {
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += RPW) {
+            const int m = m0 + rr + r, col = c + cl;
+            if (m < M && col + 8 <= c1) {
+                u32x4h* q = (u32x4h*)(p + (long long)m * pitch + col);
+                if (STORE) *q = u32x4h{(unsigned)m, (unsigned)col, 1u, 2u};
+                else { u32x4h v = *q; acc += v[0] ^ v[1] ^ v[2] ^ v[3]; }
+            }
+        }
+    }
+    if (!STORE && acc == 0x12345u) *sink = acc;
+}
+
+template <int RPW, bool STORE>
+float run(u16* p, int M, int V, long long pitch, int csplit, unsigned* sink) {
+    dim3 grid((M + 255) / 256, csplit);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) k_rows<RPW, STORE><<<grid, 512>>>(p, M, V, pitch, csplit, sink);
+    hipEventRecord(a);
+    const int it = 20;
+    for (int i = 0; i < it; ++i) k_rows<RPW, STORE><<<grid, 512>>>(p, M, V, pitch, csplit, sink);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / it * 1000.f;
+}
+
+int main() {
+    const int M = 32768;
+    u16* p; unsigned* sink;
+    hipMalloc(&p, (size_t)M * 9408 * 2 + 4096); hipMalloc(&sink, 4);
+    hipMemset(p, 0, (size_t)M * 9408 * 2);
+    const int Vs[3] = {9353, 9352, 9344};
+    for (int vi = 0; vi < 3; ++vi) {
+        const int V = Vs[vi];
+        const double gb = (double)M * V * 2 / 1e9;
+        for (int cs = 4; cs <= 16; cs *= 2) {
+            float t;
+#define ONE(RPW, ST) t = run<RPW, ST>(p, M, V, V, cs, sink); \
+            printf("V=%d csplit=%2d %s rows/wave-instr=%2d (%4d B/row): %7.1f us %7.0f GB/s\n", V, cs, ST ? "store" : "load ", RPW, 64 / RPW * 16, t, gb / t * 1e6);
+            ONE(16, true) ONE(8, true) ONE(4, true) ONE(2, true) ONE(1, true)
+            ONE(16, false) ONE(8, false) ONE(4, false) ONE(2, false) ONE(1, false)
+        }
+    }
+    hipError_t e = hipDeviceSynchronize();
+    printf("status %s\n", hipGetErrorString(e));
+    return 0;
+}

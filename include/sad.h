@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 100 /* 0.1.0 */
+#define SAD_VERSION 110 /* 0.1.1 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -95,6 +95,27 @@ typedef struct sad_bwd_args {
     int64_t dsrc_stride_t;
 } sad_bwd_args;
 
+/* Gradient tensors of the live parameters, fp32, state_dict layout (same shapes as sad_weights).
+ * A NULL field is skipped (that tensor is frozen: `requires_grad = False`, e.g. after
+ * freeze_emb(), reference classifier/models.py:151-154). */
+typedef struct sad_param_grads {
+    float* embedding_weight;
+    float* rnn_weight_ih[2];
+    float* rnn_weight_hh[2];
+    float* rnn_bias_ih[2];
+    float* rnn_bias_hh[2];
+    float* hidden_bridge0_weight;
+    float* hidden_bridge0_bias;
+    float* linear_emb_weight;
+    float* linear_emb_bias;
+    float* linear_q_weight;
+    float* linear_q_bias;
+    float* linear_attn_weight;
+    float* linear_attn_bias;
+    float* output_layer_weight;
+    float* output_layer_bias;
+} sad_param_grads;
+
 /* Named regions of the workspace, for tests / profiling (sad_workspace_field). */
 enum sad_ws_field {
     SAD_WS_LENS = 0, /* int32 [B] clamped lengths */
@@ -114,6 +135,9 @@ enum sad_ws_field {
     SAD_WS_DHFIN,    /* fp32 [B][2][Hp] */
     SAD_WS_DC,       /* fp32 [B][2][Hp] */
     SAD_WS_ACCF,     /* fp32 [T*B][Ep] split-K accumulator (small batches) */
+    SAD_WS_DL,       /* fp32 [B][L]  dlogits as used by the backward */
+    SAD_WS_DWA,      /* fp32 [B][Hp] per-sentence d linear_attn.weight */
+    SAD_WS_DSSUM,    /* fp32 [B]     per-sentence d linear_attn.bias */
     SAD_WS_NFIELDS
 };
 
@@ -143,6 +167,18 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
  * loss.backward() (reference transfer/trainers.py:376) runs through transfer/models.py:1185-1187.
  * `workspace` must be the one the matching sad_forward filled. */
 int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* workspace, void* stream);
+
+/* Parameter gradients ("unfrozen" mode): what loss.backward() leaves in `.grad` of the module's
+ * parameters when they require grad (classifier training, reference classifier/trainers.py:371-373;
+ * transfer/models.py:757-829 lists the tensors).  Call AFTER sad_backward on the same workspace
+ * (sad_backward may be called with dsrc = NULL when only parameter gradients are wanted).
+ * Every non-NULL tensor of `g` is ACCUMULATED into (+=, fp32 atomics): zero-fill for plain
+ * gradients, or keep accumulating over micro-batches.  `src` / strides are the forward's input
+ * (needed for d embedding.weight: S^T . dX for soft tokens, scatter-add for ids, where the
+ * `pad_id` row gets no gradient as with nn.Embedding(padding_idx=pad_id); pass -1 for none). */
+int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, const void* src, int32_t src_kind,
+                               int64_t src_stride_b, int64_t src_stride_t, int32_t pad_id, void* workspace,
+                               void* stream);
 
 /* Single stages, for unit tests and for timing the dominant kernels in isolation (bench.py).
  * sad_prep: length clamp + mask guard + need bits (reference transfer/models.py:865-867).

@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(Shape s, const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // K5'  backward of K5: dlogits (given, or CE(logits,labels)*dloss) -> dKk (bf16, written into the
-// key columns of DZ for EVERY t, zeros where masked) and du = d linear_q(q).
+// key columns of DZ for EVERY t, zeros where masked) and du = d linear_q(q).  Also leaves the
+// per-sentence pieces of the head's parameter gradients (used only by sad_param_grads):
+// DL = dlogits, DWA[b] = sum_t ds_t * tanh(Kk_t + u)  (d linear_attn.weight), DSSUM[b] = sum_t ds_t.
 // ------------------------------------------------------------------------------------------------
 template <int NV>
 __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restrict__ Kk, const float* __restrict__ U,
@@ -509,7 +511,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
                                                  const float* __restrict__ logits, const long long* __restrict__ labels,
                                                  const float* __restrict__ dlogits, const float* __restrict__ dloss,
                                                  float dloss_scale, const float* __restrict__ dweights,
-                                                 bf16raw* __restrict__ DZ, float* __restrict__ DU) {
+                                                 bf16raw* __restrict__ DZ, float* __restrict__ DU,
+                                                 float* __restrict__ DL, float* __restrict__ DWA,
+                                                 float* __restrict__ DSSUM) {
     __shared__ float dl[ATT_MAX_L];
     __shared__ __attribute__((aligned(16))) float dux[4][NV * 256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -529,12 +533,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
         }
     }
     __syncthreads();
-    f32x4 u[NV], w[NV], dctx[NV], du[NV];
-    float dpart = 0.f;
+    if (tid < L) DL[(long long)b * L + tid] = dl[tid];
+    f32x4 u[NV], w[NV], dctx[NV], du[NV], dwa[NV];
+    float dpart = 0.f, dssum = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int h = v * 256 + lane * 4;
-        u[v] = w[v] = dctx[v] = du[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u[v] = w[v] = dctx[v] = du[v] = dwa[v] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (h < Hp) {
             u[v] = *(const f32x4*)&U[(long long)b * Hp + h];
             w[v] = *(const f32x4*)&wa[h];
@@ -563,18 +568,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
             }
             continue;
         }
-        f32x4 kk[NV], om[NV];
+        f32x4 kk[NV], mid[NV];
         float part = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int h = v * 256 + lane * 4;
-            kk[v] = om[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kk[v] = mid[v] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (h < Hp) {
                 kk[v] = *(const f32x4*)&Kk[m * Hp + h];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float mid = tanhf_(kk[v][e] + u[v][e]);
-                    om[v][e] = 1.f - mid * mid;
+                    mid[v][e] = tanhf_(kk[v][e] + u[v][e]);
                     part += dctx[v][e] * kk[v][e];
                 }
             }
@@ -582,12 +586,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
         float da = wave_sum(part);
         if (dweights != nullptr) da += dweights[(long long)b * T + t];
         const float ds = a * (da - delta);
+        dssum += ds;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int h = v * 256 + lane * 4;
             if (h < Hp) {
-                const f32x4 dpre = om[v] * w[v] * ds;
+                const f32x4 dpre = (1.f - mid[v] * mid[v]) * w[v] * ds;
                 du[v] += dpre;
+                dwa[v] += mid[v] * ds;
                 *(u32x2*)&dz[h] = pack_bf16x4(dctx[v] * a + dpre);
             }
         }
@@ -596,6 +602,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
     for (int v = 0; v < NV; ++v) *(f32x4*)&dux[wave][v * 256 + lane * 4] = du[v];
     __syncthreads();
     for (int h = tid; h < Hp; h += 256) DU[(long long)b * Hp + h] = dux[0][h] + dux[1][h] + dux[2][h] + dux[3][h];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *(f32x4*)&dux[wave][v * 256 + lane * 4] = dwa[v];
+    if (lane == 0) dl[wave] = dssum;          // dl is dead by now (L <= 64, 4 waves)
+    __syncthreads();
+    for (int h = tid; h < Hp; h += 256) DWA[(long long)b * Hp + h] = dux[0][h] + dux[1][h] + dux[2][h] + dux[3][h];
+    if (tid == 0) DSSUM[b] = dl[0] + dl[1] + dl[2] + dl[3];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // gfx950 only.  Nothing here allocates, frees or synchronises.
 #include "../../include/sad.h"
 #include "kernels.hpp"
+#include "wgrad.hpp"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -85,6 +86,9 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_DHFIN] = B * 2 * s.Hp * 4;
     w.bytes[SAD_WS_DC] = B * 2 * s.Hp * 4;
     w.bytes[SAD_WS_ACCF] = M * s.Ep * 4;
+    w.bytes[SAD_WS_DL] = B * s.L * 4;
+    w.bytes[SAD_WS_DWA] = B * s.Hp * 4;
+    w.bytes[SAD_WS_DSSUM] = B * 4;
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -489,7 +493,9 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
         const long long* lab = (const long long*)a->labels;
 #define SAD_ATT_BWD(NV)                                                                                            \
     hipLaunchKernelGGL((k_attn_bwd<NV>), dim3(s.B), dim3(256), 0, st, s, Kk, U, wa, wo, a->weights, CTX, a->logits, \
-                       lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU)
+                       lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU,                              \
+                       at<float>(ws, wl.off[SAD_WS_DL]), at<float>(ws, wl.off[SAD_WS_DWA]),                         \
+                       at<float>(ws, wl.off[SAD_WS_DSSUM]))
         if (s.Hp <= 256) SAD_ATT_BWD(1);
         else if (s.Hp <= 512) SAD_ATT_BWD(2);
         else if (s.Hp <= 1024) SAD_ATT_BWD(4);
@@ -537,6 +543,160 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     if (a->dsrc != nullptr) {
         int rc = run_softemb_bwd(s, pl, wl, packed, ws, a->dsrc, a->dsrc_kind, a->dsrc_stride_b, a->dsrc_stride_t, st);
         if (rc) return rc;
+    }
+    return 0;
+}
+
+int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, const void* src, int32_t src_kind,
+                               int64_t sB, int64_t sT, int32_t pad_id, void* ws, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    if (check_ptr(g, "grads") || check_ptr(ws, "workspace") || check_aligned(ws, 256, "workspace")) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const WsLayout wl = ws_layout(s);
+    const int* lens = at<int>(ws, wl.off[SAD_WS_LENS]);
+    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
+    const bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
+    const bf16raw* Hs = at<bf16raw>(ws, wl.off[SAD_WS_HS]);
+    const bf16raw* DZ = at<bf16raw>(ws, wl.off[SAD_WS_DZ]);
+    const bf16raw* DX = at<bf16raw>(ws, wl.off[SAD_WS_DX]);
+    const float* Q = at<float>(ws, wl.off[SAD_WS_Q]);
+    const float* CTX = at<float>(ws, wl.off[SAD_WS_CTX]);
+    const float* DU = at<float>(ws, wl.off[SAD_WS_DU]);
+    const float* DQ = at<float>(ws, wl.off[SAD_WS_DQ]);
+    const float* DL = at<float>(ws, wl.off[SAD_WS_DL]);
+    const float* DWA = at<float>(ws, wl.off[SAD_WS_DWA]);
+    const float* DSSUM = at<float>(ws, wl.off[SAD_WS_DSSUM]);
+
+    // Row splits: enough workgroups to fill 256 CUs a few times over, whole 64-row stages per split.
+    auto row_split = [](int rows, int tiles, int* chunk) {
+        int want = ceil_div(1024, tiles < 1 ? 1 : tiles);
+        const int stages = ceil_div(rows, 64);
+        if (want > stages) want = stages;
+        if (want < 1) want = 1;
+        *chunk = ceil_div(stages, want) * 64;
+        return ceil_div(rows, *chunk);
+    };
+
+    // d embedding.weight
+    if (g->embedding_weight != nullptr) {
+        if (check_ptr(src, "src")) return -1;
+        if (src_kind == SAD_SRC_IDS) {
+            if (check_aligned(src, 8, "src")) return -1;
+            const long long chunks = (long long)s.M * (s.Ep / 4);
+            int blocks = (int)((chunks + 255) / 256);
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(k_wgrad_emb_ids, dim3(blocks), dim3(256), 0, st, s, (const long long*)src, (long long)sB,
+                               (long long)sT, DX, need, pad_id, g->embedding_weight);
+        } else if (src_kind == SAD_SRC_F32 || src_kind == SAD_SRC_BF16) {
+            if (check_aligned(src, src_kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
+            int chunk;
+            if (s.Ep == 320) {          // one n2 tile: S is read exactly once
+                typedef WCfg<128, 320, 2, 4> W;
+                const int t1 = ceil_div(s.V, W::BN1);
+                const int zs = row_split(s.M, t1, &chunk);
+                if (src_kind == SAD_SRC_F32)
+                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_F32>), dim3(t1, 1, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
+                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+                else
+                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_BF16>), dim3(t1, 1, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
+                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+            } else {
+                typedef WCfg<128, 64, 4, 1> W;
+                const int t1 = ceil_div(s.V, W::BN1), t2 = ceil_div(s.Ep, W::BN2);
+                const int zs = row_split(s.M, t1 * t2, &chunk);
+                if (src_kind == SAD_SRC_F32)
+                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_F32>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
+                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+                else
+                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_BF16>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
+                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+            }
+        } else {
+            return fail(-1, "unknown src_kind %d", src_kind);
+        }
+        SAD_CHECK_LAUNCH("k_wgrad_emb");
+    }
+    // d rnn.weight_ih (both directions), d linear_emb.weight
+    if (g->rnn_weight_ih[0] != nullptr || g->rnn_weight_ih[1] != nullptr || g->linear_emb_weight != nullptr) {
+        int chunk;
+        if (s.Ep == 320) {
+            typedef WCfg<128, 320, 2, 4> W;
+            const int t1 = ceil_div(s.Ncat, W::BN1);
+            const int zs = row_split(s.M, t1, &chunk);
+            hipLaunchKernelGGL((k_wgrad_cat<W>), dim3(t1, 1, zs), dim3(W::NT), 0, st, s, DZ, X, need, chunk,
+                               g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight);
+        } else {
+            typedef WCfg<128, 64, 4, 1> W;
+            const int t1 = ceil_div(s.Ncat, W::BN1), t2 = ceil_div(s.Ep, W::BN2);
+            const int zs = row_split(s.M, t1 * t2, &chunk);
+            hipLaunchKernelGGL((k_wgrad_cat<W>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, DZ, X, need, chunk,
+                               g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight);
+        }
+        SAD_CHECK_LAUNCH("k_wgrad_cat");
+    }
+    // d rnn.weight_hh (both directions)
+    if (g->rnn_weight_hh[0] != nullptr || g->rnn_weight_hh[1] != nullptr) {
+        typedef WCfg<128, 128, 2, 2> W;
+        const int t1 = ceil_div(s.Gp, W::BN1), t2 = ceil_div(s.Hp, W::BN2);
+        int chunk;
+        const int zs = row_split(s.M, 2 * t1 * t2, &chunk);
+        hipLaunchKernelGGL((k_wgrad_hh<W>), dim3(t1, t2, 2 * zs), dim3(W::NT), 0, st, s, DZ, Hs, need, chunk,
+                           g->rnn_weight_hh[0], g->rnn_weight_hh[1]);
+        SAD_CHECK_LAUNCH("k_wgrad_hh");
+    }
+    // LSTM biases and linear_emb.bias: column sums of DZ
+    if (g->rnn_bias_ih[0] != nullptr || g->rnn_bias_ih[1] != nullptr || g->rnn_bias_hh[0] != nullptr ||
+        g->rnn_bias_hh[1] != nullptr || g->linear_emb_bias != nullptr) {
+        const int cb = ceil_div(s.Ncat, 256);
+        int zs = ceil_div(2048, cb);
+        if (zs > ceil_div(s.M, 32)) zs = ceil_div(s.M, 32);
+        const int chunk = ceil_div(s.M, zs);
+        hipLaunchKernelGGL(k_colsum_dz, dim3(cb, ceil_div(s.M, chunk)), dim3(128), 0, st, s, DZ, chunk, g->rnn_bias_ih[0],
+                           g->rnn_bias_hh[0], g->rnn_bias_ih[1], g->rnn_bias_hh[1], g->linear_emb_bias);
+        SAD_CHECK_LAUNCH("k_colsum_dz");
+    }
+    // per-sentence dense layers
+    {
+        typedef WCfg<64, 64, 2, 2> W;
+        int chunk;
+        if (g->hidden_bridge0_weight != nullptr) {
+            const int t1 = ceil_div(s.Hp, W::BN1), t2 = ceil_div(2 * s.Hp, W::BN2);
+            const int zs = row_split(s.B, t1 * t2, &chunk);
+            hipLaunchKernelGGL((k_wgrad_dense<W, 1>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, DQ, (const void*)Hs, 2 * s.Hp,
+                               lens, chunk, g->hidden_bridge0_weight);
+        }
+        if (g->linear_q_weight != nullptr) {
+            const int t1 = ceil_div(s.Hp, W::BN1), t2 = ceil_div(s.Hp, W::BN2);
+            const int zs = row_split(s.B, t1 * t2, &chunk);
+            hipLaunchKernelGGL((k_wgrad_dense<W, 0>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, DU, (const void*)Q, s.Hp, lens,
+                               chunk, g->linear_q_weight);
+        }
+        SAD_CHECK_LAUNCH("k_wgrad_dense");
+    }
+    // small reductions over sentences
+    {
+        auto colsum = [&](const float* srcp, int cols, int ld, float* dst) {
+            if (dst == nullptr) return;
+            int zs = ceil_div(s.B, 64);
+            if (zs > 64) zs = 64;
+            const int chunk = ceil_div(s.B, zs);
+            hipLaunchKernelGGL(k_colsum_f32, dim3(ceil_div(cols, 256), ceil_div(s.B, chunk)), dim3(256), 0, st, srcp, s.B, cols,
+                               ld, chunk, dst);
+        };
+        colsum(DQ, s.H, s.Hp, g->hidden_bridge0_bias);
+        colsum(DU, s.H, s.Hp, g->linear_q_bias);
+        colsum(DWA, s.H, s.Hp, g->linear_attn_weight);
+        colsum(DSSUM, 1, 1, g->linear_attn_bias);
+        colsum(DL, s.L, s.L, g->output_layer_bias);
+        if (g->output_layer_weight != nullptr) {
+            int zs = ceil_div(s.B, 64);
+            if (zs > 64) zs = 64;
+            const int chunk = ceil_div(s.B, zs);
+            hipLaunchKernelGGL(k_wgrad_head, dim3(ceil_div(s.H, 256), ceil_div(s.B, chunk)), dim3(256), 0, st, s, DL, CTX, chunk,
+                               g->output_layer_weight);
+        }
+        SAD_CHECK_LAUNCH("k_colsum_f32");
     }
     return 0;
 }

@@ -1,0 +1,422 @@
+// Parameter gradients of the discriminator ("unfrozen" mode: classifier training, and the mode the
+// data-parallel all-reduce of SURVEY.md §8 d1/e1 refers to).  The reference gets these from autograd
+// (loss.backward(), classifier/trainers.py:371-373) for the 19 live tensors of
+// transfer/models.py:757-829; here each is one reduction over the token rows m = t*B + b:
+//
+//   dW[n1][n2] += sum_m A[m][n1] * B[m][n2]                         ("TN" GEMM, K = token rows)
+//
+// Both operands are stored row-major in m (the reduced index is the SLOW index), which is the
+// opposite of what an MFMA fragment wants (8 consecutive k per lane).  gfx950's
+// ds_read_b64_tr_b16 does the transpose on the way out of LDS: tiles are staged row-major exactly
+// as they sit in HBM (coalesced 16-byte loads, no scatter) and read back column-major.
+//
+//  * LDS tile: [64 token rows][BN columns] bf16, row pitch 2*BN + 32 bytes.  pitch/32 is odd, so
+//    the 8 rows a 32-lane half touches in one transposed read start 8 dwords apart mod 64 banks:
+//    conflict-free.
+//  * k assignment inside a 32-row slab: lane group g = lane>>4 holds rows {4g..4g+3} u {16+4g..16+4g+3}
+//    (two transposed reads).  Any assignment works as long as both operands use the same one.
+//  * Results are ACCUMULATED (+=) with fp32 atomics straight into the caller's state_dict-layout
+//    tensors (gate rows un-permuted, padding dropped in the epilogue): split-K over token rows needs
+//    no staging buffer, and gradient accumulation over micro-batches / the flat all-reduce bucket
+//    come for free.
+#pragma once
+#include "kernels.hpp"
+
+namespace sad {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int BN1_, int BN2_, int W1_, int W2_>
+struct WCfg {
+    static constexpr int BN1 = BN1_, BN2 = BN2_, W1 = W1_, W2 = W2_, BK = 64;
+    static constexpr int NT = 64 * W1_ * W2_;
+    static constexpr int T1 = BN1_ / W1_ / 16, T2 = BN2_ / W2_ / 16;
+    static constexpr int P1 = BN1_ * 2 + 32, P2 = BN2_ * 2 + 32;   // LDS row pitch, bytes
+    static constexpr int CPR1 = BN1_ / 8, CPR2 = BN2_ / 8;         // 16-byte chunks per tile row
+    static constexpr int CH1 = BK * CPR1 / NT, CH2 = BK * CPR2 / NT;
+    static_assert(BN1_ % 32 == 0 && BN2_ % 32 == 0, "pitch/32 must be odd");
+    static_assert(BN1_ % (W1_ * 16) == 0 && BN2_ % (W2_ * 16) == 0, "tile/wave mismatch");
+    static_assert((BK * CPR1) % NT == 0 && (BK * CPR2) % NT == 0, "staging must divide evenly");
+};
+
+// 8 k-values (rows r .. r+3 and r+16 .. r+19 of the slab) of one column; see file header.
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int pitch) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * pitch));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// row_ok(m) -> bool : token row m contributes (both operands are skipped otherwise)
+// load_a(m, c) / load_b(m, c) -> u32x4 : 8 bf16 of columns [c, c+8) of the block tile, row m
+// acc[t1][t2]: lane holds dW[n1 = w1*(BN1/W1) + 16*t1 + (lane&15)][n2 = w2*(BN2/W2) + 16*t2 + 4*(lane>>4) + e]
+template <class W, class OK, class LA, class LB>
+__device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA load_a, LB load_b,
+                                           f32x4 (&acc)[W::T1][W::T2], unsigned char* As, unsigned char* Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w1 = wave / W::W2, w2 = wave % W::W2;
+    u32x4 ra[W::CH1], rb[W::CH2];
+    int any_r = 0;
+    auto issue = [&](int m0) {
+        any_r = 0;
+#pragma unroll
+        for (int i = 0; i < W::CH1; ++i) {
+            const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1, m = m0 + r;
+            const bool ok = m < m_end && row_ok(m);
+            ra[i] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) ra[i] = load_a(m, c * 8);
+            any_r |= ok ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < W::CH2; ++i) {
+            const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2, m = m0 + r;
+            const bool ok = m < m_end && row_ok(m);
+            rb[i] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) rb[i] = load_b(m, c * 8);
+        }
+    };
+    const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
+    const unsigned char* abase = As + rowsel * W::P1 + (w1 * (W::BN1 / W::W1) + p4) * 2;
+    const unsigned char* bbase = Bs + rowsel * W::P2 + (w2 * (W::BN2 / W::W2) + p4) * 2;
+    issue(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += W::BK) {
+        __syncthreads();                       // every wave is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < W::CH1; ++i) {
+            const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1;
+            *(u32x4*)(As + r * W::P1 + c * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W::CH2; ++i) {
+            const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
+            *(u32x4*)(Bs + r * W::P2 + c * 16) = rb[i];
+        }
+        const int any = __syncthreads_or(any_r);
+        if (m0 + W::BK < m_end) issue(m0 + W::BK);   // next tile's loads fly under the MFMAs
+        if (any) {                                 // block-uniform: EXEC stays full for the transposed reads
+#pragma unroll
+            for (int ks = 0; ks < W::BK / 32; ++ks) {
+                bf16x8 fa[W::T1], fb[W::T2];
+#pragma unroll
+                for (int t1 = 0; t1 < W::T1; ++t1) fa[t1] = tr_frag(abase + ks * 32 * W::P1 + t1 * 32, W::P1);
+#pragma unroll
+                for (int t2 = 0; t2 < W::T2; ++t2) fb[t2] = tr_frag(bbase + ks * 32 * W::P2 + t2 * 32, W::P2);
+#pragma unroll
+                for (int t1 = 0; t1 < W::T1; ++t1)
+#pragma unroll
+                    for (int t2 = 0; t2 < W::T2; ++t2)
+                        acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[t2], fa[t1], acc[t1][t2], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <class W>
+__device__ __forceinline__ void wgrad_zero(f32x4 (&acc)[W::T1][W::T2]) {
+#pragma unroll
+    for (int t1 = 0; t1 < W::T1; ++t1)
+#pragma unroll
+        for (int t2 = 0; t2 < W::T2; ++t2) acc[t1][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// epi(n1, n2, v): v = dW[n1][n2 .. n2+3] (block-tile-relative indices)
+template <class W, class Epi>
+__device__ __forceinline__ void wgrad_epilogue(const f32x4 (&acc)[W::T1][W::T2], Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w1 = wave / W::W2, w2 = wave % W::W2;
+#pragma unroll
+    for (int t1 = 0; t1 < W::T1; ++t1)
+#pragma unroll
+        for (int t2 = 0; t2 < W::T2; ++t2)
+            epi(w1 * (W::BN1 / W::W1) + 16 * t1 + (lane & 15), w2 * (W::BN2 / W::W2) + 16 * t2 + 4 * (lane >> 4), acc[t1][t2]);
+}
+
+// dst[0..3] += v[0..3] for the elements below `limit` (hardware fp32 atomics)
+__device__ __forceinline__ void atomic_add4(float* dst, int col, int limit, f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (col + e < limit) unsafeAtomicAdd(dst + e, v[e]);
+}
+
+// Packed (permuted) gate column -> row of a torch [4H, *] LSTM parameter, or -1 for padding.
+__device__ __forceinline__ int gate_row(int pc, int H) {
+    const int unit = (pc >> 6) * 16 + (pc & 15), gate = (pc & 63) >> 4;
+    return unit < H ? gate * H + unit : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// d rnn.weight_ih_l0{,_reverse} [4H,E] and d linear_emb.weight [H,E]:  dWcat = DZ^T . X
+// (autograd of nn.LSTM's input GEMMs, transfer/models.py:906, and of linear_emb, :925)
+// grid: (Ncat/BN1, Ep/BN2, row splits)
+// ------------------------------------------------------------------------------------------------
+template <class W>
+__global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __restrict__ DZ,
+                                                    const bf16raw* __restrict__ X,
+                                                    const unsigned char* __restrict__ need, int mchunk,
+                                                    float* __restrict__ gih0, float* __restrict__ gih1,
+                                                    float* __restrict__ glin) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
+    const int m_begin = blockIdx.z * mchunk, m_end = min(s.M, m_begin + mchunk);
+    const int Ncat = s.Ncat, Ep = s.Ep;
+    // skip column blocks whose destination is absent (frozen tensors)
+    {
+        const int lo = n10, hi = min(Ncat, n10 + W::BN1) - 1;
+        const bool w0 = gih0 != nullptr && lo < s.Gp, w1 = gih1 != nullptr && hi >= s.Gp && lo < 2 * s.Gp;
+        const bool w2 = glin != nullptr && hi >= 2 * s.Gp;
+        if (!(w0 || w1 || w2)) return;
+    }
+    f32x4 acc[W::T1][W::T2];
+    wgrad_zero<W>(acc);
+    wgrad_core<W>(
+        m_begin, m_end, [&](int m) { return need[m] != 0; },
+        [&](int m, int c) {
+            const int n = n10 + c;
+            return n < Ncat ? *(const u32x4*)(DZ + (long long)m * Ncat + n) : u32x4{0u, 0u, 0u, 0u};
+        },
+        [&](int m, int c) {
+            const int n = n20 + c;
+            return n < Ep ? *(const u32x4*)(X + (long long)m * Ep + n) : u32x4{0u, 0u, 0u, 0u};
+        },
+        acc, As, Bs);
+    const int E = s.E, H = s.H, Gp = s.Gp;
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+        const int n1 = n10 + r1, n2 = n20 + r2;
+        if (n1 >= Ncat || n2 >= E) return;
+        float* dst = nullptr;
+        if (n1 < 2 * Gp) {
+            const int dir = n1 >= Gp ? 1 : 0;
+            const int row = gate_row(n1 - dir * Gp, H);
+            float* g = dir ? gih1 : gih0;
+            if (row >= 0 && g != nullptr) dst = g + (long long)row * E + n2;
+        } else {
+            const int j = n1 - 2 * Gp;
+            if (j < H && glin != nullptr) dst = glin + (long long)j * E + n2;
+        }
+        if (dst != nullptr) atomic_add4(dst, n2, E, v);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// d rnn.weight_hh_l0{,_reverse} [4H,H]:  dWhh[d] = sum_t dZ_t[d]^T . h_{prev(t)}[d]
+// h_prev of token row m = (t,b): forward direction Hs[t-1][b] (zero state at t = 0), reverse
+// direction Hs[t+1][b] (zero state at t = len-1).  grid: (Gp/BN1, Hp/BN2, 2 * row splits)
+// ------------------------------------------------------------------------------------------------
+template <class W>
+__global__ __launch_bounds__(W::NT) void k_wgrad_hh(Shape s, const bf16raw* __restrict__ DZ,
+                                                   const bf16raw* __restrict__ Hs,
+                                                   const unsigned char* __restrict__ need, int mchunk,
+                                                   float* __restrict__ ghh0, float* __restrict__ ghh1) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    const int dir = blockIdx.z & 1;
+    float* g = dir ? ghh1 : ghh0;
+    if (g == nullptr) return;
+    const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
+    const int m_begin = (blockIdx.z >> 1) * mchunk, m_end = min(s.M, m_begin + mchunk);
+    const int Ncat = s.Ncat, Hp = s.Hp, Gp = s.Gp, B = s.B, M = s.M;
+    const long long shift = dir ? B : -B;         // token-row offset of the previous recurrence step
+    f32x4 acc[W::T1][W::T2];
+    wgrad_zero<W>(acc);
+    wgrad_core<W>(
+        m_begin, m_end,
+        [&](int m) { return dir ? (m + B < M && (need[m + B] & 1)) : (m >= B && (need[m] & 1)); },
+        [&](int m, int c) {
+            const int n = n10 + c;
+            return n < Gp ? *(const u32x4*)(DZ + (long long)m * Ncat + dir * Gp + n) : u32x4{0u, 0u, 0u, 0u};
+        },
+        [&](int m, int c) {
+            const int n = n20 + c;
+            return n < Hp ? *(const u32x4*)(Hs + ((m + shift) * 2 + dir) * Hp + n) : u32x4{0u, 0u, 0u, 0u};
+        },
+        acc, As, Bs);
+    const int H = s.H;
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+        const int n1 = n10 + r1, n2 = n20 + r2;
+        if (n1 >= Gp || n2 >= H) return;
+        const int row = gate_row(n1, H);
+        if (row >= 0) atomic_add4(g + (long long)row * H + n2, n2, H, v);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// d embedding.weight [V,E], soft tokens:  dW_emb = S^T . dX   (autograd of `src @ embedding.weight`,
+// transfer/models.py:898; every vocabulary row including the pad row receives gradient).
+// grid: (Vp/BN1, Ep/BN2, row splits)
+// ------------------------------------------------------------------------------------------------
+template <class W, int KIND>
+__global__ __launch_bounds__(W::NT) void k_wgrad_emb(Shape s, const void* __restrict__ src, long long sT, long long sB,
+                                                    const bf16raw* __restrict__ DX,
+                                                    const unsigned char* __restrict__ need, int mchunk,
+                                                    float* __restrict__ gemb) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    typedef SoftRow<KIND> SR;
+    typedef typename SR::Elem Elem;
+    const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
+    const int m_begin = blockIdx.z * mchunk, m_end = min(s.M, m_begin + mchunk);
+    const int V = s.V, Ep = s.Ep, B = s.B;
+    f32x4 acc[W::T1][W::T2];
+    wgrad_zero<W>(acc);
+    wgrad_core<W>(
+        m_begin, m_end, [&](int m) { return need[m] != 0; },
+        [&](int m, int c) {
+            const int t = m / B, b = m - t * B;
+            const Elem* row = (const Elem*)src + (long long)t * sT + (long long)b * sB;
+            return typename SR::Cvt()(SR::load(row, n10 + c, V));
+        },
+        [&](int m, int c) {
+            const int n = n20 + c;
+            return n < Ep ? *(const u32x4*)(DX + (long long)m * Ep + n) : u32x4{0u, 0u, 0u, 0u};
+        },
+        acc, As, Bs);
+    const int E = s.E;
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+        const int n1 = n10 + r1, n2 = n20 + r2;
+        if (n1 < V && n2 < E) atomic_add4(gemb + (long long)n1 * E + n2, n2, E, v);
+    });
+}
+
+// d embedding.weight, hard tokens: scatter-add of dX rows (autograd of nn.Embedding,
+// transfer/models.py:900; the padding_idx row gets no gradient, :770-775).
+__global__ void k_wgrad_emb_ids(Shape s, const long long* __restrict__ ids, long long ib, long long it,
+                                const bf16raw* __restrict__ DX, const unsigned char* __restrict__ need, int pad_id,
+                                float* __restrict__ gemb) {
+    const int cpr = s.Ep / 4;
+    const long long total = (long long)s.M * cpr;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(c / cpr), e = (int)(c - (long long)m * cpr) * 4;
+        if (!need[m] || e >= s.E) continue;
+        const int t = m / s.B, b = m - t * s.B;
+        const long long id = ids[(long long)b * ib + (long long)t * it];
+        if (id < 0 || id >= s.V || id == pad_id) continue;
+        const u32x2 raw = *(const u32x2*)(DX + (long long)m * s.Ep + e);
+        const f32x4 v = f32x4{bf16_to_f32((bf16raw)(raw[0] & 0xffffu)), bf16_to_f32((bf16raw)(raw[0] >> 16)),
+                              bf16_to_f32((bf16raw)(raw[1] & 0xffffu)), bf16_to_f32((bf16raw)(raw[1] >> 16))};
+        atomic_add4(gemb + id * s.E + e, e, s.E, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-sentence dense layers: d hidden_bridges.0.weight [H,2H] = dq^T . [h_fwd | h_rev]
+// (transfer/models.py:929-934) and d linear_q.weight [H,H] = du^T . q (:855).  K = B sentences.
+// BKIND 0: B operand fp32 [rows][ldb];  1: the [h_fwd(len-1) | h_rev(0)] gather out of Hs.
+// grid: (Hp/BN1, N2/BN2, row splits)
+// ------------------------------------------------------------------------------------------------
+template <class W, int BKIND>
+__global__ __launch_bounds__(W::NT) void k_wgrad_dense(Shape s, const float* __restrict__ A, const void* __restrict__ Bop,
+                                                      int N2p, const int* __restrict__ lens, int mchunk,
+                                                      float* __restrict__ g) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
+    const int m_begin = blockIdx.z * mchunk, m_end = min(s.B, m_begin + mchunk);
+    const int Hp = s.Hp, B = s.B;
+    auto load_f32 = [](const float* p) {
+        return pack_bf16x8(*(const f32x4*)p, *(const f32x4*)(p + 4));
+    };
+    f32x4 acc[W::T1][W::T2];
+    wgrad_zero<W>(acc);
+    wgrad_core<W>(
+        m_begin, m_end, [&](int b) { return BKIND == 0 || lens[b] > 0; },
+        [&](int b, int c) {
+            const int n = n10 + c;
+            return n < Hp ? load_f32(A + (long long)b * Hp + n) : u32x4{0u, 0u, 0u, 0u};
+        },
+        [&](int b, int c) {
+            const int n = n20 + c;
+            if (n >= N2p) return u32x4{0u, 0u, 0u, 0u};
+            if constexpr (BKIND == 0) {
+                return load_f32((const float*)Bop + (long long)b * N2p + n);
+            } else {
+                const int d = n >= Hp ? 1 : 0;
+                const int ts = d ? 0 : lens[b] - 1;
+                return *(const u32x4*)((const bf16raw*)Bop + (((long long)ts * B + b) * 2 + d) * Hp + (n - d * Hp));
+            }
+        },
+        acc, As, Bs);
+    const int H = s.H;
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+        const int n1 = n10 + r1, n2 = n20 + r2;
+        if (n1 >= H || n2 >= N2p) return;
+        if constexpr (BKIND == 0) {
+            if (n2 < H) atomic_add4(g + (long long)n1 * H + n2, n2, H, v);
+        } else {
+            const int d = n2 >= Hp ? 1 : 0, j = n2 - d * Hp;
+            if (j < H) atomic_add4(g + (long long)n1 * 2 * H + d * H + j, j, H, v);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bias gradients = column sums.
+// k_colsum_dz: DZ [M][Ncat] bf16 -> d rnn.bias_ih/hh (both get the same sum, nn.LSTM adds the two
+// biases) and d linear_emb.bias.  grid: (Ncat/256, row splits), 128 threads x 2 columns.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_colsum_dz(Shape s, const bf16raw* __restrict__ DZ, int mchunk,
+                                                  float* __restrict__ bih0, float* __restrict__ bhh0,
+                                                  float* __restrict__ bih1, float* __restrict__ bhh1,
+                                                  float* __restrict__ blin) {
+    const int n = blockIdx.x * 256 + threadIdx.x * 2;
+    if (n >= s.Ncat) return;
+    const int m_begin = blockIdx.y * mchunk, m_end = min(s.M, m_begin + mchunk);
+    float a0 = 0.f, a1 = 0.f, c0 = 0.f, c1 = 0.f;
+    int m = m_begin;
+    for (; m + 1 < m_end; m += 2) {                 // two independent chains
+        const unsigned u = *(const unsigned*)(DZ + (long long)m * s.Ncat + n);
+        const unsigned w = *(const unsigned*)(DZ + (long long)(m + 1) * s.Ncat + n);
+        a0 += bf16_to_f32((bf16raw)(u & 0xffffu));
+        a1 += bf16_to_f32((bf16raw)(u >> 16));
+        c0 += bf16_to_f32((bf16raw)(w & 0xffffu));
+        c1 += bf16_to_f32((bf16raw)(w >> 16));
+    }
+    if (m < m_end) {
+        const unsigned u = *(const unsigned*)(DZ + (long long)m * s.Ncat + n);
+        a0 += bf16_to_f32((bf16raw)(u & 0xffffu));
+        a1 += bf16_to_f32((bf16raw)(u >> 16));
+    }
+    const float sum[2] = {a0 + c0, a1 + c1};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int col = n + e;
+        if (col < 2 * s.Gp) {
+            const int dir = col >= s.Gp ? 1 : 0;
+            const int row = gate_row(col - dir * s.Gp, s.H);
+            if (row < 0) continue;
+            float* bi = dir ? bih1 : bih0;
+            float* bh = dir ? bhh1 : bhh0;
+            if (bi != nullptr) unsafeAtomicAdd(bi + row, sum[e]);
+            if (bh != nullptr) unsafeAtomicAdd(bh + row, sum[e]);
+        } else {
+            const int j = col - 2 * s.Gp;
+            if (j < s.H && blin != nullptr) unsafeAtomicAdd(blin + j, sum[e]);
+        }
+    }
+}
+
+// dst[c] += sum_r src[r][c], c < cols.  grid: (ceil(cols/256), row splits)
+__global__ __launch_bounds__(256) void k_colsum_f32(const float* __restrict__ src, int rows, int cols, int ld, int rchunk,
+                                                   float* __restrict__ dst) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * rchunk, r1 = min(rows, r0 + rchunk);
+    float a = 0.f;
+    for (int r = r0; r < r1; ++r) a += src[(long long)r * ld + c];
+    unsafeAtomicAdd(dst + c, a);
+}
+
+// d output_layer.weight [L,H] += dl^T . ctx  (transfer/models.py:949).  grid: (ceil(H/256), row splits)
+__global__ __launch_bounds__(256) void k_wgrad_head(Shape s, const float* __restrict__ DL, const float* __restrict__ CTX,
+                                                   int rchunk, float* __restrict__ gwo) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= s.H) return;
+    const int r0 = blockIdx.y * rchunk, r1 = min(s.B, r0 + rchunk);
+    for (int c = 0; c < s.L; ++c) {
+        float a = 0.f;
+        for (int b = r0; b < r1; ++b) a += DL[(long long)b * s.L + c] * CTX[(long long)b * s.Hp + h];
+        unsafeAtomicAdd(gwo + (long long)c * s.H + h, a);
+    }
+}
+
+}  // namespace sad

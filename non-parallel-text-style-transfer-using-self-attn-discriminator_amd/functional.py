@@ -156,11 +156,50 @@ def _is_dense(shape, strides):
     return True
 
 
+def _grad_struct(views):
+    """name -> tensor (or missing = frozen)  ->  sad_param_grads."""
+    g = _lib.SadParamGrads()
+
+    def p(name):
+        t = views.get(name)
+        return t.data_ptr() if t is not None else None
+
+    g.embedding_weight = p("embedding.weight")
+    for i, sfx in enumerate(("", "_reverse")):
+        g.rnn_weight_ih[i] = p("rnn.weight_ih_l0" + sfx)
+        g.rnn_weight_hh[i] = p("rnn.weight_hh_l0" + sfx)
+        g.rnn_bias_ih[i] = p("rnn.bias_ih_l0" + sfx)
+        g.rnn_bias_hh[i] = p("rnn.bias_hh_l0" + sfx)
+    g.hidden_bridge0_weight = p("hidden_bridges.0.weight")
+    g.hidden_bridge0_bias = p("hidden_bridges.0.bias")
+    g.linear_emb_weight = p("linear_emb.weight")
+    g.linear_emb_bias = p("linear_emb.bias")
+    g.linear_q_weight = p("linear_q.weight")
+    g.linear_q_bias = p("linear_q.bias")
+    g.linear_attn_weight = p("linear_attn.weight")
+    g.linear_attn_bias = p("linear_attn.bias")
+    g.output_layer_weight = p("output_layer.weight")
+    g.output_layer_bias = p("output_layer.bias")
+    return g
+
+
+_N_FIXED = 7   # forward() arguments in front of *params
+
+
 class _Discriminator(torch.autograd.Function):
+    """forward(src, lengths, mask, labels, pw, guard, pad_id, *params).
+
+    ``params`` is either empty (frozen discriminator: the transfer loop, reference
+    transfer/trainers.py:216-223) or the 19 live parameters in ``_LIVE_PARAMS`` order; those that
+    require grad receive gradients from sad_param_grads_accumulate (classifier training, reference
+    classifier/trainers.py:367-373)."""
+
     @staticmethod
-    def forward(ctx, src, lengths_dev, mask, labels, pw, guard):
+    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, *params):
         if not src.is_cuda:
             raise RuntimeError("sad_amd runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
+        if params and len(params) != len(_LIVE_PARAMS):
+            raise RuntimeError("expected %d live parameters, got %d" % (len(_LIVE_PARAMS), len(params)))
         kind = _src_kind(src)
         B, T = src.shape[0], src.shape[1]
         if kind != _lib.SRC_IDS:
@@ -191,9 +230,13 @@ class _Discriminator(torch.autograd.Function):
             _lib.check(_lib.load().sad_forward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
                                                _stream_ptr()), "sad_forward")
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(*([] if kind != _lib.SRC_IDS else [logits, weights] + ([loss] if loss is not None else [])))
-        ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype, labels, logits, weights)
-        ctx.last_ws = ws
+        any_param = any(ctx.needs_input_grad[_N_FIXED:])
+        if kind == _lib.SRC_IDS and not any_param:
+            ctx.mark_non_differentiable(*([logits, weights] + ([loss] if loss is not None else [])))
+        # the forward input is needed again for d embedding.weight (S^T . dX / scatter-add by id)
+        keep_src = src if (params and ctx.needs_input_grad[_N_FIXED]) else None
+        ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype, labels, logits, weights, keep_src,
+                   -1 if pad_id is None else int(pad_id), [tuple(p.shape) for p in params])
         _Discriminator.last_workspace = ws   # introspection hook for tests / profiling
         if loss is None:
             return logits, weights
@@ -201,11 +244,14 @@ class _Discriminator(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits, dweights, dloss=None):
-        d, ws, pw, kind, shape, strides, dtype, labels, logits, weights = ctx.sad
-        if kind == _lib.SRC_IDS:
-            return None, None, None, None, None, None
+        d, ws, pw, kind, shape, strides, dtype, labels, logits, weights, src, pad_id, pshapes = ctx.sad
+        n_out = _N_FIXED + len(pshapes)
+        want_src = kind != _lib.SRC_IDS and ctx.needs_input_grad[0]
+        want_p = [bool(x) for x in ctx.needs_input_grad[_N_FIXED:]]
+        if not want_src and not any(want_p):
+            return (None,) * n_out
         dev = logits.device
-        B, T, V = shape
+        B = shape[0]
         if dlogits is not None and dloss is not None:
             p = torch.softmax(logits, dim=1)
             p[torch.arange(B, device=dev), labels] -= 1.0
@@ -213,17 +259,19 @@ class _Discriminator(torch.autograd.Function):
             dloss = None
         if dlogits is None and dloss is None:
             if dweights is None:
-                return None, None, None, None, None, None
+                return (None,) * n_out
             dlogits = torch.zeros_like(logits)
-        # dS keeps the memory layout of S (time-major in the transfer loop) so the generator's
-        # autograd consumes it without a transposing copy.
-        if _is_dense(shape, strides):
-            dsrc = torch.empty_strided(shape, strides, dtype=dtype, device=dev)
-        else:
-            dsrc = torch.empty(shape, dtype=dtype, device=dev)
+        dsrc = None
+        if want_src:
+            # dS keeps the memory layout of S (time-major in the transfer loop) so the generator's
+            # autograd consumes it without a transposing copy.
+            if _is_dense(shape, strides):
+                dsrc = torch.empty_strided(shape, strides, dtype=dtype, device=dev)
+            else:
+                dsrc = torch.empty(shape, dtype=dtype, device=dev)
         a = _lib.SadBwdArgs()
-        a.dlogits = dlogits.contiguous().data_ptr() if dlogits is not None else None
-        keep = dlogits
+        keep = dlogits = dlogits.to(torch.float32).contiguous() if dlogits is not None else None
+        a.dlogits = dlogits.data_ptr() if dlogits is not None else None
         a.labels = labels.data_ptr() if labels is not None else None
         if dloss is not None:
             dloss = dloss.to(torch.float32).contiguous()
@@ -233,24 +281,54 @@ class _Discriminator(torch.autograd.Function):
             dweights = dweights.to(torch.float32).contiguous()
             a.dweights = dweights.data_ptr()
         a.logits, a.weights = logits.data_ptr(), weights.data_ptr()
-        a.dsrc, a.dsrc_kind = dsrc.data_ptr(), kind
-        a.dsrc_stride_b, a.dsrc_stride_t = dsrc.stride(0), dsrc.stride(1)
+        if dsrc is not None:
+            a.dsrc, a.dsrc_kind = dsrc.data_ptr(), kind
+            a.dsrc_stride_b, a.dsrc_stride_t = dsrc.stride(0), dsrc.stride(1)
+        pgrads = [None] * len(pshapes)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().sad_backward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
-                                                _stream_ptr()), "sad_backward")
+            lib = _lib.load()
+            _lib.check(lib.sad_backward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf), _stream_ptr()),
+                       "sad_backward")
+            if any(want_p):
+                # one flat zero-filled bucket, one view per live tensor: the kernels accumulate into
+                # it, and a data-parallel caller can all-reduce the bucket as a single message.
+                sizes = [int(torch.Size(s).numel()) if w else 0 for s, w in zip(pshapes, want_p)]
+                flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+                views, off = {}, 0
+                for i, (name, s, w) in enumerate(zip(_LIVE_PARAMS, pshapes, want_p)):
+                    if w:
+                        pgrads[i] = flat[off:off + sizes[i]].view(s)
+                        views[name] = pgrads[i]
+                        off += sizes[i]
+                g = _grad_struct(views)
+                sp = src.data_ptr() if src is not None else None
+                sb, st_ = (strides[0], strides[1])
+                _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d), ctypes.byref(g), sp, kind, sb, st_, pad_id,
+                                                          _ptr(ws.buf), _stream_ptr()), "sad_param_grads_accumulate")
+                _Discriminator.last_grad_bucket = flat
         del keep
-        return dsrc, None, None, None, None, None
+        return (dsrc, None, None, None, None, None, None) + tuple(pgrads)
 
 
-def discriminator(src, src_len, mask, pw, guard=True):
-    """(logits [B,L], attention weights [B,T]) — the reference module's return value."""
+def _live(params):
+    """Mapping / None -> tuple of the 19 live tensors in kernel order (empty = frozen)."""
+    if not params:
+        return ()
+    return tuple(params[n] for n in _LIVE_PARAMS)
+
+
+def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None):
+    """(logits [B,L], attention weights [B,T]) — the reference module's return value.
+
+    ``params`` (name -> nn.Parameter, optional) makes the call differentiable w.r.t. the parameters
+    that require grad; without it the discriminator is frozen (gradient flows to soft tokens only)."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard)
+    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, *_live(params))
 
 
-def discriminator_loss(src, src_len, mask, labels, pw, guard=True):
+def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None):
     """(per-sentence CE loss [B], logits, weights) with the cross entropy fused into the attention
     kernels — what the transfer step computes at reference transfer/models.py:1185-1212."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard)
+    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, *_live(params))
     return loss, logits, weights

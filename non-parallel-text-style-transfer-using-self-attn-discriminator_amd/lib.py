@@ -15,12 +15,12 @@ LIB_PATH = os.environ.get("SAD_LIB") or os.path.join(_HERE, "_native", "libsad.s
 SRC_IDS, SRC_F32, SRC_BF16 = 0, 1, 2
 
 WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", "DX", "DU", "DQ",
-             "DHFIN", "DC", "ACCF")
+             "DHFIN", "DC", "ACCF", "DL", "DWA", "DSSUM")
 
 # every symbol include/sad.h declares (tests/test_cabi.py checks the .so exports all of them)
 EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",
            "sad_workspace_bytes", "sad_workspace_field", "sad_pack_weights", "sad_forward",
-           "sad_backward", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd")
+           "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd")
 
 
 class SadDims(ctypes.Structure):
@@ -45,6 +45,10 @@ class SadWeights(ctypes.Structure):
         ("output_layer_weight", c_void_p),
         ("output_layer_bias", c_void_p),
     ]
+
+
+class SadParamGrads(SadWeights):
+    """sad_param_grads: same tensors as sad_weights, writable; NULL = frozen tensor."""
 
 
 class SadFwdArgs(ctypes.Structure):
@@ -90,6 +94,8 @@ def load():
     lib.sad_pack_weights.argtypes = [POINTER(SadDims), POINTER(SadWeights), c_void_p, c_void_p]
     lib.sad_forward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadFwdArgs), c_void_p, c_void_p]
     lib.sad_backward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadBwdArgs), c_void_p, c_void_p]
+    lib.sad_param_grads_accumulate.argtypes = [POINTER(SadDims), POINTER(SadParamGrads), c_void_p, c_int32, c_int64,
+                                               c_int64, c_int32, c_void_p, c_void_p]
     lib.sad_prep.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]
     lib.sad_softemb_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]
     lib.sad_softemb_bwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]

@@ -84,12 +84,14 @@ class _SelfAttnBase(nn.Module):
             self._pw_key = key
         return self._pw
 
-    def _check_frozen(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._live().values()):
-            raise NotImplementedError(
-                "sad_amd round 1 back-propagates to the soft tokens with FROZEN discriminator parameters "
-                "(the transfer loop's mode, reference transfer/trainers.py:216-223). Freeze the module "
-                "(`for p in m.parameters(): p.requires_grad = False`) or call it under torch.no_grad().")
+    def _trainable(self):
+        """The live parameters when the call must be differentiable w.r.t. them (classifier training,
+        reference classifier/trainers.py:367-373), else None: the frozen transfer-loop mode
+        (reference transfer/trainers.py:216-223) skips every weight-gradient kernel."""
+        live = self._live()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in live.values()):
+            return live
+        return None
 
     def _run(self, src, src_len, mask, hidden, soft, guard):
         if hidden is not None:
@@ -98,15 +100,15 @@ class _SelfAttnBase(nn.Module):
             raise RuntimeError("soft=True expects [B,T,V] soft tokens")
         if not soft and src.dim() != 2:
             raise RuntimeError("soft=False expects [B,T] token ids")
-        self._check_frozen()
-        return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard)
+        return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard, params=self._trainable(),
+                                pad_id=self.embedding.padding_idx)
 
     def loss(self, src, src_len, mask, labels, soft=True):
         """Fused variant: per-sentence CE vs ``labels`` computed inside the attention kernels
         (reference transfer/models.py:1185-1212). Returns (loss [B], logits, weights)."""
-        self._check_frozen()
         return Fn.discriminator_loss(src, src_len, mask, labels, self.packed_weights(),
-                                     guard=self._flavour == "transfer")
+                                     guard=self._flavour == "transfer", params=self._trainable(),
+                                     pad_id=self.embedding.padding_idx)
 
 
 class TransferSelfAttnRNNClassifier(_SelfAttnBase):

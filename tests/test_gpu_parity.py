@@ -36,6 +36,81 @@ def _oracle(params, S_bt, lengths, mask, labels, soft=True, dloss=None, dweights
     return f, b
 
 
+def _oracle_grads(params, src, lengths, mask, labels, soft=True, guard=True, dtype=np.float64):
+    p = O.cast_params(params, dtype)
+    f = O.forward(p, src.astype(dtype) if soft else src, lengths, mask.copy(), soft, labels=labels, guard=guard)
+    B = len(labels)
+    dl = O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B))
+    return f, O.backward(p, f["cache"], dl, want_param_grads=True)
+
+
+def _grad_errors(got, want):
+    errs = {}
+    for k, w in want.items():
+        g = got[k]
+        assert g is not None and g.shape == w.shape, k
+        assert np.isfinite(g).all(), k
+        # linear_attn.bias has an analytically zero gradient (softmax shift invariance): floor the scale
+        errs[k] = relerr(g, w, floor=1e-3)
+    return errs
+
+
+BF16_TOL_WGRAD = 2e-2
+
+
+@pytest.mark.parametrize("kind", ["dense", "onehot"])
+def test_param_grads_tiny_golden(kind):
+    """Unfrozen mode: all 19 live parameter gradients vs the reference's autograd (golden fixture
+    written by tools/gen_golden.py from the imported reference module, mean CE loss)."""
+    hdr, d, params, want = load_golden("tiny_soft_%s_f32.npz" % kind)
+    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2))
+    out = run_sad(params, S_bt, d["lengths"], d["mask"], d["labels"], param_grads=True)
+    assert len(want) == 19
+    errs = _grad_errors(out["grads"], want)
+    errs["dS"] = relerr(out["dS"].transpose(1, 0, 2), d["dS"])
+    _report("param grads tiny golden %s" % kind, errs)
+    assert max(errs.values()) < BF16_TOL_WGRAD, errs
+
+
+def test_param_grads_tiny_hard_golden():
+    """Hard tokens (classifier training, classifier/trainers.py:367): gradients incl. the embedding
+    scatter-add; the padding_idx row stays zero."""
+    hdr, d, params, want = load_golden("tiny_hard_f64.npz")
+    out = run_sad(params, d["ids"], d["lengths"], d["mask"], d["labels"], soft=False, param_grads=True, pad_id=0)
+    assert len(want) == 19
+    errs = _grad_errors(out["grads"], want)
+    _report("param grads tiny hard golden", errs)
+    assert max(errs.values()) < BF16_TOL_WGRAD, errs
+    assert not out["grads"]["embedding.weight"][0].any()
+
+
+def test_param_grads_ragged_vs_oracle_and_frozen_subset():
+    """Odd sizes (H, E not multiples of the tile sizes, ragged lengths, several row splits) vs the
+    oracle; then the same call with the embedding frozen (freeze_emb) and one bias frozen: frozen
+    tensors get no gradient, the others are unchanged up to atomics' summation order."""
+    V, E, H, B, T = 203, 44, 24, 37, 13
+    lengths = np.sort(np.random.RandomState(5).randint(2, T + 1, size=B))[::-1].astype(np.int32)
+    lengths[0] = T
+    params = synth.make_params(V, E, H, seed=21)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=9, kind="dense", time_major=False)
+    labels = synth.make_labels(B, seed=4)
+    mask = synth.transfer_mask(lengths, T)
+    out = run_sad(params, S, lengths, mask, labels, param_grads=True)
+    f, b = _oracle_grads(params, S, lengths, mask, labels)
+    errs = _grad_errors(out["grads"], b["grads"])
+    errs["dS"] = relerr(out["dS"], b["dS"])
+    _report("param grads ragged", errs)
+    assert max(errs.values()) < BF16_TOL_WGRAD, errs
+    frozen = ("embedding.weight", "linear_q.bias")
+    out2 = run_sad(params, S, lengths, mask, labels, param_grads=True, frozen=frozen)
+    for k, v in out2["grads"].items():
+        if k in frozen:
+            assert v is None
+        else:
+            assert relerr(v, out["grads"][k], floor=1e-6) < 1e-4, k
+    assert np.array_equal(out2["dS"], out["dS"])
+
+
 def test_stages_tiny_exact_inputs():
     """Every workspace stage against the oracle on inputs that are exactly representable in bf16
     (one-hot S, bf16-rounded weights): the GEMM stages must then agree to fp32-accumulate accuracy,

@@ -44,16 +44,24 @@ def bf16_round(x):
 
 
 def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", time_major=True,
-            dloss=None, fused_loss=True, guard=True, want_ws=False, dweights=None):
+            dloss=None, fused_loss=True, guard=True, want_ws=False, dweights=None, param_grads=False,
+            frozen=(), pad_id=None):
     """Run libsad forward (+ backward when soft) on cuda:0 through the Python binding.
 
     src: numpy [B,T,V] float / [B,T] int64 (batch-major, like the oracle takes it).
+    param_grads: also back-propagate into the parameters (all but the names in `frozen`);
+    out["grads"] = {name: numpy}.
     Returns dict of numpy arrays (logits, weights, loss, mask_after, dS [B,T,V], ws fields)."""
     import torch
     from sad_amd import functional as Fn
     dev = torch.device("cuda:0")
     tp = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in params.items()}
     pw = Fn.pack_weights(tp)
+    live = None
+    if param_grads:
+        live = {k: tp[k] for k in Fn._LIVE_PARAMS}
+        for k, v in live.items():
+            v.requires_grad_(k not in frozen)
     B, T = src.shape[:2]
     if soft:
         tdt = torch.float32 if s_dtype == "f32" else torch.bfloat16
@@ -71,24 +79,27 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
     out = {}
     if labels is not None and fused_loss:
         lab = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(dev)
-        loss, logits, weights = Fn.discriminator_loss(x, ln, m, lab, pw, guard=guard)
+        loss, logits, weights = Fn.discriminator_loss(x, ln, m, lab, pw, guard=guard, params=live, pad_id=pad_id)
     else:
-        logits, weights = Fn.discriminator(x, ln, m, pw, guard=guard)
+        logits, weights = Fn.discriminator(x, ln, m, pw, guard=guard, params=live, pad_id=pad_id)
         loss = None
         if labels is not None:
             lab = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(dev)
             loss = torch.nn.functional.cross_entropy(logits, lab, reduction="none")
     ws = Fn._Discriminator.last_workspace
-    if soft and loss is not None:
+    if (soft or param_grads) and loss is not None:
         up = torch.full((B,), 1.0 / B, device=dev) if dloss is None else torch.from_numpy(
             np.asarray(dloss, dtype=np.float32)).to(dev)
         tot = (loss * up).sum()
         if dweights is not None:
             tot = tot + (weights * torch.from_numpy(np.asarray(dweights, dtype=np.float32)).to(dev)).sum()
         tot.backward()
-        out["dS"] = S.grad.float().cpu().numpy()
-        out["dS_strides"] = tuple(S.grad.stride())
-        out["S_strides"] = tuple(S.stride())
+        if soft:
+            out["dS"] = S.grad.float().cpu().numpy()
+            out["dS_strides"] = tuple(S.grad.stride())
+            out["S_strides"] = tuple(S.stride())
+        if param_grads:
+            out["grads"] = {k: (None if v.grad is None else v.grad.cpu().numpy()) for k, v in live.items()}
     torch.cuda.synchronize()
     out.update(logits=logits.detach().cpu().numpy(), weights=weights.detach().cpu().numpy(),
                loss=None if loss is None else loss.detach().cpu().numpy(), mask_after=m.cpu().numpy())

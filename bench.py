@@ -157,6 +157,44 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
+    # --- unfrozen mode: + parameter gradients, + one all-reduce of the flat grad
+    # bucket over RCCL when N > 1, + re-packing the weights (an optimizer step invalidates the image).
+    live = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in params.items() if k in Fn._LIVE_PARAMS}
+
+    def step_unfrozen():
+        Sv.grad = None
+        for p_ in live.values():
+            p_.grad = None
+        pw.pack(live)
+        loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, params=live, pad_id=0)
+        (loss.sum() / (B * world)).backward()
+        if world > 1:
+            dist.all_reduce(Fn._Discriminator.last_grad_bucket)
+        return loss
+
+    u_steps = max(1, min(a.steps, 10))
+    for _ in range(2):
+        step_unfrozen()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(u_steps):
+        step_unfrozen()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el_u = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el_u], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el_u = float(tt.item())
+    # leave a frozen step's workspace behind for the per-kernel timing below
+    step()
+    torch.cuda.synchronize()
+
     out = None
     if rank == 0:
         # --- roofline of the dominant kernels, timed in isolation on the launch stream ----------
@@ -213,6 +251,11 @@ def main():
                        "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
                        "mfma_inputs": "bf16", "accumulate": "fp32"},
             "roofline": roofline, "cpu_baseline": cpu,
+            "unfrozen": {"value": round(world * B * u_steps / el_u, 1), "unit": "sentences/s", "steps": u_steps,
+                         "ms_per_step": round(el_u / u_steps * 1e3, 4),
+                         "what": "same batch, + all 19 parameter gradients + weight re-pack"
+                                 + (" + all-reduce of the %.1f MB fp32 grad bucket (RCCL)" % (
+                                     Fn._Discriminator.last_grad_bucket.numel() * 4 / 1e6) if world > 1 else "")},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -84,6 +84,34 @@ def test_param_grads_tiny_hard_golden():
     assert not out["grads"]["embedding.weight"][0].any()
 
 
+@pytest.mark.parametrize("s_dtype", ["f32", "bf16"])
+def test_param_grads_yelp_dims(s_dtype):
+    """Yelp dims (V=9353, E=300, H=512): the shipped-size kernel configurations (one 320-wide
+    tile over E).  Small tensors vs the reference's golden gradients, every tensor vs the oracle."""
+    hdr, d, _, gold = load_golden("yelp_soft_dense_f32.npz")
+    V, E, H, B, T = (hdr[k] for k in "VEHBT")
+    params = synth.make_params(V, E, H, seed=hdr["param_seed"])
+    S = synth.make_soft_tokens(B, T, V, d["lengths"], seed=hdr["s_seed"], kind="dense", time_major=False)
+    out = run_sad(params, S, d["lengths"], d["mask"], d["labels"], s_dtype=s_dtype, param_grads=True)
+    f, b = _oracle_grads(params, S, d["lengths"], d["mask"], d["labels"])
+    errs = _grad_errors(out["grads"], b["grads"])
+    for k, w in gold.items():
+        errs["golden:" + k] = relerr(out["grads"][k], w, floor=1e-3)
+    _report("param grads yelp dims %s" % s_dtype, errs)
+    assert max(errs.values()) < BF16_TOL_WGRAD, errs
+
+
+def test_param_grads_yelp_hard_b64():
+    """Classifier-training shape on real Yelp sentences (hard tokens, B=64) vs the oracle."""
+    hdr, d, _, _ = load_golden("yelp_hard_b64.npz")
+    params = synth.make_params(hdr["V"], hdr["E"], hdr["H"], seed=hdr["param_seed"])
+    out = run_sad(params, d["ids"], d["lengths"], d["mask"], d["labels"], soft=False, param_grads=True, pad_id=0)
+    f, b = _oracle_grads(params, d["ids"], d["lengths"], d["mask"], d["labels"], soft=False)
+    errs = _grad_errors(out["grads"], b["grads"])
+    _report("param grads yelp hard b64", errs)
+    assert max(errs.values()) < BF16_TOL_WGRAD, errs
+
+
 def test_param_grads_ragged_vs_oracle_and_frozen_subset():
     """Odd sizes (H, E not multiples of the tile sizes, ragged lengths, several row splits) vs the
     oracle; then the same call with the embedding frozen (freeze_emb) and one bias frozen: frozen
@@ -258,11 +286,40 @@ def test_module_dropin_both_flavours():
     if margin > 0.05:
         assert np.array_equal(style_src.cpu().numpy(), d["gms_style_src"])
         assert np.array_equal(content_src.cpu().numpy(), d["gms_content_src"])
-    # unfrozen parameters with grad enabled are refused loudly, not silently mistrained
+    # one classifier-training step through the module API (reference classifier/trainers.py:367-373):
+    # gradients land in .grad of the live parameters, dead ones stay None, clip + optimizer step work,
+    # and the next forward uses the updated weights (packed image is refreshed).
+    _, _, _, gold = load_golden("tiny_hard_f64.npz")
     for p in mt.parameters():
         p.requires_grad = True
-    with pytest.raises(NotImplementedError):
-        mt(ids, torch.from_numpy(d["lengths"]), mask)
+    opt = torch.optim.SGD(mt.parameters(), lr=0.5)
+    lab = torch.from_numpy(d["labels"]).cuda()
+    mask = torch.from_numpy(d["mask"].copy()).cuda()
+    logits, _ = mt(ids, torch.from_numpy(d["lengths"]), mask)
+    loss = torch.nn.functional.cross_entropy(logits, lab)
+    opt.zero_grad()
+    loss.backward()
+    got = {k: p.grad for k, p in mt.named_parameters()}
+    for k in synth.DEAD_PARAMS:
+        assert got[k] is None
+    for k, w_ in gold.items():
+        assert relerr(got[k].cpu().numpy(), w_, floor=1e-3) < BF16_TOL_WGRAD, k
+    torch.nn.utils.clip_grad_norm_(mt.parameters(), 5.0)
+    opt.step()
+    new_params = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in mt.state_dict().items()}
+    mask = torch.from_numpy(d["mask"].copy()).cuda()
+    with torch.no_grad():
+        logits2, _ = mt(ids, torch.from_numpy(d["lengths"]), mask)
+    f2 = O.forward(new_params, d["ids"], d["lengths"], d["mask"].copy(), False, labels=d["labels"])
+    assert relerr(logits2.cpu().numpy(), f2["logits"]) < BF16_TOL_FWD
+    assert relerr(logits2.cpu().numpy(), d["logits"]) > 1e-3      # the step really moved the weights
+    # freeze_emb(): no embedding gradient, the rest still trains
+    mt.freeze_emb()
+    opt.zero_grad(set_to_none=True)
+    mask = torch.from_numpy(d["mask"].copy()).cuda()
+    logits, _ = mt(ids, torch.from_numpy(d["lengths"]), mask)
+    torch.nn.functional.cross_entropy(logits, lab).backward()
+    assert mt.embedding.weight.grad is None and mt.linear_q.weight.grad is not None
 
 
 def _cfg3_inputs(B, T=32, V=9353, seed=1234):

@@ -568,9 +568,10 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     const float* DWA = at<float>(ws, wl.off[SAD_WS_DWA]);
     const float* DSSUM = at<float>(ws, wl.off[SAD_WS_DSSUM]);
 
-    // Row splits: enough workgroups to fill 256 CUs a few times over, whole 64-row stages per split.
+    // Row splits: ~2 workgroups per CU (every split costs one atomic add per output element), whole
+    // 64-row stages per split.
     auto row_split = [](int rows, int tiles, int* chunk) {
-        int want = ceil_div(1024, tiles < 1 ? 1 : tiles);
+        int want = ceil_div(512, tiles < 1 ? 1 : tiles);
         const int stages = ceil_div(rows, 64);
         if (want > stages) want = stages;
         if (want < 1) want = 1;

@@ -47,38 +47,53 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int pitch) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// row_ok(m) -> bool : token row m contributes (both operands are skipped otherwise)
+// row_ok(m) -> bool : token row m contributes (both operands are skipped otherwise); may read memory
 // load_a(m, c) / load_b(m, c) -> u32x4 : 8 bf16 of columns [c, c+8) of the block tile, row m
-// acc[t1][t2]: lane holds dW[n1 = w1*(BN1/W1) + 16*t1 + (lane&15)][n2 = w2*(BN2/W2) + 16*t2 + 4*(lane>>4) + e]
+// acc[t1][t2][e]: dW[n1 = w1*(BN1/W1) + 16*t1 + 4*(lane>>4) + e][n2 = w2*(BN2/W2) + 16*t2 + (lane&15)]
+// (plain operand order: 16 lanes hold 16 CONSECUTIVE n2 of one row -> 64-byte atomic segments).
+//
+// Pipeline: the row predicates of stage k+2 and the operand tiles of stage k+1 are in flight while
+// stage k is multiplied, so a predicate's latency never sits in front of its tile's loads.
 template <class W, class OK, class LA, class LB>
 __device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA load_a, LB load_b,
                                            f32x4 (&acc)[W::T1][W::T2], unsigned char* As, unsigned char* Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w1 = wave / W::W2, w2 = wave % W::W2;
     u32x4 ra[W::CH1], rb[W::CH2];
-    int any_r = 0;
-    auto issue = [&](int m0) {
-        any_r = 0;
+    auto flags = [&](int m0) {              // bit i: chunk i of this thread sits on a contributing row
+        unsigned f = 0;
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
-            const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1, m = m0 + r;
-            const bool ok = m < m_end && row_ok(m);
-            ra[i] = u32x4{0u, 0u, 0u, 0u};
-            if (ok) ra[i] = load_a(m, c * 8);
-            any_r |= ok ? 1 : 0;
+            const int m = m0 + (tid + i * W::NT) / W::CPR1;
+            if (m < m_end && row_ok(m)) f |= 1u << i;
         }
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
-            const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2, m = m0 + r;
-            const bool ok = m < m_end && row_ok(m);
+            const int m = m0 + (tid + i * W::NT) / W::CPR2;
+            if (m < m_end && row_ok(m)) f |= 1u << (W::CH1 + i);
+        }
+        return f;
+    };
+    auto issue = [&](int m0, unsigned f) {
+#pragma unroll
+        for (int i = 0; i < W::CH1; ++i) {
+            const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1;
+            ra[i] = u32x4{0u, 0u, 0u, 0u};
+            if (f & (1u << i)) ra[i] = load_a(m0 + r, c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < W::CH2; ++i) {
+            const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
             rb[i] = u32x4{0u, 0u, 0u, 0u};
-            if (ok) rb[i] = load_b(m, c * 8);
+            if (f & (1u << (W::CH1 + i))) rb[i] = load_b(m0 + r, c * 8);
         }
     };
     const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
     const unsigned char* abase = As + rowsel * W::P1 + (w1 * (W::BN1 / W::W1) + p4) * 2;
     const unsigned char* bbase = Bs + rowsel * W::P2 + (w2 * (W::BN2 / W::W2) + p4) * 2;
-    issue(m_begin);
+    unsigned fcur = flags(m_begin);
+    unsigned fnext = m_begin + W::BK < m_end ? flags(m_begin + W::BK) : 0u;
+    issue(m_begin, fcur);
     for (int m0 = m_begin; m0 < m_end; m0 += W::BK) {
         __syncthreads();                       // every wave is done reading the previous tile
 #pragma unroll
@@ -91,8 +106,10 @@ __device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA
             const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
             *(u32x4*)(Bs + r * W::P2 + c * 16) = rb[i];
         }
-        const int any = __syncthreads_or(any_r);
-        if (m0 + W::BK < m_end) issue(m0 + W::BK);   // next tile's loads fly under the MFMAs
+        const int any = __syncthreads_or(fcur != 0u);
+        fcur = fnext;
+        if (m0 + W::BK < m_end) issue(m0 + W::BK, fcur);            // next tile's loads fly under the MFMAs
+        fnext = m0 + 2 * W::BK < m_end ? flags(m0 + 2 * W::BK) : 0u;
         if (any) {                                 // block-uniform: EXEC stays full for the transposed reads
 #pragma unroll
             for (int ks = 0; ks < W::BK / 32; ++ks) {
@@ -105,7 +122,7 @@ __device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA
                 for (int t1 = 0; t1 < W::T1; ++t1)
 #pragma unroll
                     for (int t2 = 0; t2 < W::T2; ++t2)
-                        acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[t2], fa[t1], acc[t1][t2], 0, 0, 0);
+                        acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t1], fb[t2], acc[t1][t2], 0, 0, 0);
             }
         }
     }
@@ -119,7 +136,8 @@ __device__ __forceinline__ void wgrad_zero(f32x4 (&acc)[W::T1][W::T2]) {
         for (int t2 = 0; t2 < W::T2; ++t2) acc[t1][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// epi(n1, n2, v): v = dW[n1][n2 .. n2+3] (block-tile-relative indices)
+// epi(n1, n2, v): v = dW[n1][n2] (block-tile-relative indices); per call the 16 lanes of a group
+// hold 16 consecutive n2 of one row n1.
 template <class W, class Epi>
 __device__ __forceinline__ void wgrad_epilogue(const f32x4 (&acc)[W::T1][W::T2], Epi epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -128,7 +146,10 @@ __device__ __forceinline__ void wgrad_epilogue(const f32x4 (&acc)[W::T1][W::T2],
     for (int t1 = 0; t1 < W::T1; ++t1)
 #pragma unroll
         for (int t2 = 0; t2 < W::T2; ++t2)
-            epi(w1 * (W::BN1 / W::W1) + 16 * t1 + (lane & 15), w2 * (W::BN2 / W::W2) + 16 * t2 + 4 * (lane >> 4), acc[t1][t2]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                epi(w1 * (W::BN1 / W::W1) + 16 * t1 + 4 * (lane >> 4) + e, w2 * (W::BN2 / W::W2) + 16 * t2 + (lane & 15),
+                    acc[t1][t2][e]);
 }
 
 // dst[0..3] += v[0..3] for the elements below `limit` (hardware fp32 atomics)
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
         },
         acc, As, Bs);
     const int E = s.E, H = s.H, Gp = s.Gp;
-    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
         if (n1 >= Ncat || n2 >= E) return;
         float* dst = nullptr;
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
             const int j = n1 - 2 * Gp;
             if (j < H && glin != nullptr) dst = glin + (long long)j * E + n2;
         }
-        if (dst != nullptr) atomic_add4(dst, n2, E, v);
+        if (dst != nullptr) unsafeAtomicAdd(dst, v);
     });
 }
 
@@ -232,11 +253,11 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_hh(Shape s, const bf16raw* __re
         },
         acc, As, Bs);
     const int H = s.H;
-    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
         if (n1 >= Gp || n2 >= H) return;
         const int row = gate_row(n1, H);
-        if (row >= 0) atomic_add4(g + (long long)row * H + n2, n2, H, v);
+        if (row >= 0) unsafeAtomicAdd(g + (long long)row * H + n2, v);
     });
 }
 
@@ -272,9 +293,9 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_emb(Shape s, const void* __rest
         },
         acc, As, Bs);
     const int E = s.E;
-    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
-        if (n1 < V && n2 < E) atomic_add4(gemb + (long long)n1 * E + n2, n2, E, v);
+        if (n1 < V && n2 < E) unsafeAtomicAdd(gemb + (long long)n1 * E + n2, v);
     });
 }
 
@@ -337,14 +358,14 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_dense(Shape s, const float* __r
         },
         acc, As, Bs);
     const int H = s.H;
-    wgrad_epilogue<W>(acc, [&](int r1, int r2, f32x4 v) {
+    wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
         if (n1 >= H || n2 >= N2p) return;
         if constexpr (BKIND == 0) {
-            if (n2 < H) atomic_add4(g + (long long)n1 * H + n2, n2, H, v);
+            if (n2 < H) unsafeAtomicAdd(g + (long long)n1 * H + n2, v);
         } else {
             const int d = n2 >= Hp ? 1 : 0, j = n2 - d * Hp;
-            if (j < H) atomic_add4(g + (long long)n1 * 2 * H + d * H + j, j, H, v);
+            if (j < H) unsafeAtomicAdd(g + (long long)n1 * 2 * H + d * H + j, v);
         }
     });
 }

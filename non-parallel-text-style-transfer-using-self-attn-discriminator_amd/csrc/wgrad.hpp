@@ -26,9 +26,10 @@ namespace sad {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int BN1_, int BN2_, int W1_, int W2_>
+template <int BN1_, int BN2_, int W1_, int W2_, int NS_ = 2>
 struct WCfg {
     static constexpr int BN1 = BN1_, BN2 = BN2_, W1 = W1_, W2 = W2_, BK = 64;
+    static constexpr int NS = NS_;                                 // 64-row tiles of global loads in flight
     static constexpr int NT = 64 * W1_ * W2_;
     static constexpr int T1 = BN1_ / W1_ / 16, T2 = BN2_ / W2_ / 16;
     static constexpr int P1 = BN1_ * 2 + 32, P2 = BN2_ * 2 + 32;   // LDS row pitch, bytes
@@ -47,85 +48,120 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int pitch) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// row_ok(m) -> bool : token row m contributes (both operands are skipped otherwise); may read memory
-// load_a(m, c) / load_b(m, c) -> u32x4 : 8 bf16 of columns [c, c+8) of the block tile, row m
+// row_ok(m) -> bool : token row m (always in [m_begin, m_end)) contributes; may read memory, must be
+//                     BRANCH-FREE (clamp indices instead of guarding the load)
+// load_a(m, c, ok) / load_b(m, c, ok) -> u32x4 : 8 bf16 of columns [c, c+8) of the block tile, row m;
+//                     zeros when !ok; must be BRANCH-FREE (load from a dummy address, then select)
 // acc[t1][t2][e]: dW[n1 = w1*(BN1/W1) + 16*t1 + 4*(lane>>4) + e][n2 = w2*(BN2/W2) + 16*t2 + (lane&15)]
 // (plain operand order: 16 lanes hold 16 CONSECUTIVE n2 of one row -> 64-byte atomic segments).
 //
-// Pipeline: the row predicates of stage k+2 and the operand tiles of stage k+1 are in flight while
-// stage k is multiplied, so a predicate's latency never sits in front of its tile's loads.
+// Pipeline: NS tiles of operand loads (register ring, statically indexed) and the row predicates of
+// the two tiles after them are in flight while a tile is multiplied.  Everything in the loop issues
+// a STATIC number of memory operations, so hipcc keeps counted s_waitcnt vmcnt(N) and only the
+// oldest tile is waited for (any control flow around a load makes it drain the whole ring).
 template <class W, class OK, class LA, class LB>
 __device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA load_a, LB load_b,
                                            f32x4 (&acc)[W::T1][W::T2], unsigned char* As, unsigned char* Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w1 = wave / W::W2, w2 = wave % W::W2;
-    u32x4 ra[W::CH1], rb[W::CH2];
-    auto flags = [&](int m0) {              // bit i: chunk i of this thread sits on a contributing row
+    constexpr int NS = W::NS;
+    u32x4 ra[NS][W::CH1], rb[NS][W::CH2];
+    unsigned fl[NS];                          // predicate bits of the tile held by each ring slot
+    const int nk = (m_end - m_begin + W::BK - 1) / W::BK;
+    auto flags = [&](int kt) {                // bit i: chunk i of this thread sits on a contributing row
+        const int m0 = m_begin + kt * W::BK;
         unsigned f = 0;
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
             const int m = m0 + (tid + i * W::NT) / W::CPR1;
-            if (m < m_end && row_ok(m)) f |= 1u << i;
+            const bool ok = row_ok(m < m_end ? m : m_end - 1) && m < m_end;
+            f |= ok ? 1u << i : 0u;
         }
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
             const int m = m0 + (tid + i * W::NT) / W::CPR2;
-            if (m < m_end && row_ok(m)) f |= 1u << (W::CH1 + i);
+            const bool ok = row_ok(m < m_end ? m : m_end - 1) && m < m_end;
+            f |= ok ? 1u << (W::CH1 + i) : 0u;
         }
-        return f;
+        return kt < nk ? f : 0u;
     };
-    auto issue = [&](int m0, unsigned f) {
+    auto issue = [&](auto slot, int kt, unsigned f) {
+        constexpr int sl = decltype(slot)::value;
+        const int m0 = m_begin + kt * W::BK;
+        fl[sl] = f;
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1;
-            ra[i] = u32x4{0u, 0u, 0u, 0u};
-            if (f & (1u << i)) ra[i] = load_a(m0 + r, c * 8);
+            ra[sl][i] = load_a(m0 + r, c * 8, (f >> i) & 1u);
         }
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
-            rb[i] = u32x4{0u, 0u, 0u, 0u};
-            if (f & (1u << (W::CH1 + i))) rb[i] = load_b(m0 + r, c * 8);
+            rb[sl][i] = load_b(m0 + r, c * 8, (f >> (W::CH1 + i)) & 1u);
         }
     };
     const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
     const unsigned char* abase = As + rowsel * W::P1 + (w1 * (W::BN1 / W::W1) + p4) * 2;
     const unsigned char* bbase = Bs + rowsel * W::P2 + (w2 * (W::BN2 / W::W2) + p4) * 2;
-    unsigned fcur = flags(m_begin);
-    unsigned fnext = m_begin + W::BK < m_end ? flags(m_begin + W::BK) : 0u;
-    issue(m_begin, fcur);
-    for (int m0 = m_begin; m0 < m_end; m0 += W::BK) {
+    auto consume = [&](auto slot) {            // ring slot -> LDS -> MFMAs
+        constexpr int sl = decltype(slot)::value;
         __syncthreads();                       // every wave is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1;
-            *(u32x4*)(As + r * W::P1 + c * 16) = ra[i];
+            *(u32x4*)(As + r * W::P1 + c * 16) = ra[sl][i];
         }
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
-            *(u32x4*)(Bs + r * W::P2 + c * 16) = rb[i];
+            *(u32x4*)(Bs + r * W::P2 + c * 16) = rb[sl][i];
         }
-        const int any = __syncthreads_or(fcur != 0u);
-        fcur = fnext;
-        if (m0 + W::BK < m_end) issue(m0 + W::BK, fcur);            // next tile's loads fly under the MFMAs
-        fnext = m0 + 2 * W::BK < m_end ? flags(m0 + 2 * W::BK) : 0u;
-        if (any) {                                 // block-uniform: EXEC stays full for the transposed reads
+        return __syncthreads_or(fl[sl] != 0u);
+    };
+    auto mfma_tile = [&]() {
 #pragma unroll
-            for (int ks = 0; ks < W::BK / 32; ++ks) {
-                bf16x8 fa[W::T1], fb[W::T2];
+        for (int ks = 0; ks < W::BK / 32; ++ks) {
+            bf16x8 fa[W::T1], fb[W::T2];
 #pragma unroll
-                for (int t1 = 0; t1 < W::T1; ++t1) fa[t1] = tr_frag(abase + ks * 32 * W::P1 + t1 * 32, W::P1);
+            for (int t1 = 0; t1 < W::T1; ++t1) fa[t1] = tr_frag(abase + ks * 32 * W::P1 + t1 * 32, W::P1);
 #pragma unroll
-                for (int t2 = 0; t2 < W::T2; ++t2) fb[t2] = tr_frag(bbase + ks * 32 * W::P2 + t2 * 32, W::P2);
+            for (int t2 = 0; t2 < W::T2; ++t2) fb[t2] = tr_frag(bbase + ks * 32 * W::P2 + t2 * 32, W::P2);
 #pragma unroll
-                for (int t1 = 0; t1 < W::T1; ++t1)
+            for (int t1 = 0; t1 < W::T1; ++t1)
 #pragma unroll
-                    for (int t2 = 0; t2 < W::T2; ++t2)
-                        acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t1], fb[t2], acc[t1][t2], 0, 0, 0);
-            }
+                for (int t2 = 0; t2 < W::T2; ++t2)
+                    acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t1], fb[t2], acc[t1][t2], 0, 0, 0);
         }
+    };
+    // Prologue: predicates of the first NS+2 tiles, then NS tiles of loads (tiles past the end have
+    // all-zero predicates: their loads hit the dummy address and return zeros).
+    unsigned f0 = 0, f1 = 0;                   // predicates of the next two tiles to be issued
+    static_for<NS>([&](auto slot) { issue(slot, decltype(slot)::value, flags(decltype(slot)::value)); });
+    f0 = flags(NS);
+    f1 = flags(NS + 1);
+    const int groups = (nk + NS - 1) / NS;
+    for (int gk = 0; gk < groups; ++gk) {
+        static_for<NS>([&](auto slot) {
+            const int kt = gk * NS + decltype(slot)::value;
+            const int any = consume(slot);
+            issue(slot, kt + NS, f0);          // refill this slot (zeros past the end)
+            f0 = f1;
+            f1 = flags(kt + NS + 2);
+            if (any) mfma_tile();              // block-uniform: EXEC stays full for the transposed reads
+        });
     }
+}
+
+// Branch-free 16-byte load: `ok ? *p : 0`, reading `dummy` instead when !ok.
+__device__ __forceinline__ u32x4 load16_if(const void* p, const void* dummy, bool ok) {
+    const u32x4 v = *(const u32x4*)(ok ? p : dummy);
+    return ok ? v : u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ u32x4 load8f_if(const float* p, const float* dummy, bool ok) {
+    const float* q = ok ? p : dummy;
+    const f32x4 lo = *(const f32x4*)q, hi = *(const f32x4*)(q + 4);
+    const u32x4 v = pack_bf16x8(lo, hi);
+    return ok ? v : u32x4{0u, 0u, 0u, 0u};
 }
 
 template <class W>
@@ -192,13 +228,13 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
     wgrad_zero<W>(acc);
     wgrad_core<W>(
         m_begin, m_end, [&](int m) { return need[m] != 0; },
-        [&](int m, int c) {
+        [&](int m, int c, bool ok) {
             const int n = n10 + c;
-            return n < Ncat ? *(const u32x4*)(DZ + (long long)m * Ncat + n) : u32x4{0u, 0u, 0u, 0u};
+            return load16_if(DZ + (long long)m * Ncat + n, DZ, ok && n < Ncat);
         },
-        [&](int m, int c) {
+        [&](int m, int c, bool ok) {
             const int n = n20 + c;
-            return n < Ep ? *(const u32x4*)(X + (long long)m * Ep + n) : u32x4{0u, 0u, 0u, 0u};
+            return load16_if(X + (long long)m * Ep + n, X, ok && n < Ep);
         },
         acc, As, Bs);
     const int E = s.E, H = s.H, Gp = s.Gp;
@@ -242,14 +278,17 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_hh(Shape s, const bf16raw* __re
     wgrad_zero<W>(acc);
     wgrad_core<W>(
         m_begin, m_end,
-        [&](int m) { return dir ? (m + B < M && (need[m + B] & 1)) : (m >= B && (need[m] & 1)); },
-        [&](int m, int c) {
-            const int n = n10 + c;
-            return n < Gp ? *(const u32x4*)(DZ + (long long)m * Ncat + dir * Gp + n) : u32x4{0u, 0u, 0u, 0u};
+        [&](int m) {
+            const bool inr = dir ? (m + B < M) : (m >= B);
+            return inr && (need[inr && dir ? m + B : m] & 1);
         },
-        [&](int m, int c) {
+        [&](int m, int c, bool ok) {
+            const int n = n10 + c;
+            return load16_if(DZ + (long long)m * Ncat + dir * Gp + n, DZ, ok && n < Gp);
+        },
+        [&](int m, int c, bool ok) {
             const int n = n20 + c;
-            return n < Hp ? *(const u32x4*)(Hs + ((m + shift) * 2 + dir) * Hp + n) : u32x4{0u, 0u, 0u, 0u};
+            return load16_if(Hs + ((m + shift) * 2 + dir) * Hp + n, Hs, ok && n < Hp);
         },
         acc, As, Bs);
     const int H = s.H;
@@ -280,18 +319,28 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_emb(Shape s, const void* __rest
     const int V = s.V, Ep = s.Ep, B = s.B;
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
-    wgrad_core<W>(
-        m_begin, m_end, [&](int m) { return need[m] != 0; },
-        [&](int m, int c) {
-            const int t = m / B, b = m - t * B;
-            const Elem* row = (const Elem*)src + (long long)t * sT + (long long)b * sB;
-            return typename SR::Cvt()(SR::load(row, n10 + c, V));
-        },
-        [&](int m, int c) {
-            const int n = n20 + c;
-            return n < Ep ? *(const u32x4*)(DX + (long long)m * Ep + n) : u32x4{0u, 0u, 0u, 0u};
-        },
-        acc, As, Bs);
+    auto row_ok = [&](int m) { return need[m] != 0; };
+    auto load_b = [&](int m, int c, bool ok) {
+        const int n = n20 + c;
+        return load16_if(DX + (long long)m * Ep + n, DX, ok && n < Ep);
+    };
+    auto s_row = [&](int m, bool ok) -> const Elem* {
+        const int t = m / B, b = m - t * B;
+        return ok ? (const Elem*)src + (long long)t * sT + (long long)b * sB : nullptr;
+    };
+    if (n10 + W::BN1 <= V) {     // interior vocabulary tile: whole chunks, branch-free loads
+        wgrad_core<W>(
+            m_begin, m_end, row_ok,
+            [&](int m, int c, bool ok) {
+                return typename SR::Cvt()(SR::load_fast(s_row(m, ok), (const Elem*)src, n10 + c));
+            },
+            load_b, acc, As, Bs);
+    } else {                     // the tile holding the ragged end of V: element-guarded loads
+        wgrad_core<W>(
+            m_begin, m_end, row_ok,
+            [&](int m, int c, bool ok) { return typename SR::Cvt()(SR::load(s_row(m, ok), n10 + c, V)); }, load_b, acc,
+            As, Bs);
+    }
     const int E = s.E;
     wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
@@ -334,26 +383,23 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_dense(Shape s, const float* __r
     const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
     const int m_begin = blockIdx.z * mchunk, m_end = min(s.B, m_begin + mchunk);
     const int Hp = s.Hp, B = s.B;
-    auto load_f32 = [](const float* p) {
-        return pack_bf16x8(*(const f32x4*)p, *(const f32x4*)(p + 4));
-    };
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
     wgrad_core<W>(
         m_begin, m_end, [&](int b) { return BKIND == 0 || lens[b] > 0; },
-        [&](int b, int c) {
+        [&](int b, int c, bool ok) {
             const int n = n10 + c;
-            return n < Hp ? load_f32(A + (long long)b * Hp + n) : u32x4{0u, 0u, 0u, 0u};
+            return load8f_if(A + (long long)b * Hp + n, A, ok && n < Hp);
         },
-        [&](int b, int c) {
+        [&](int b, int c, bool ok) {
             const int n = n20 + c;
-            if (n >= N2p) return u32x4{0u, 0u, 0u, 0u};
+            const bool ok2 = ok && n < N2p;
             if constexpr (BKIND == 0) {
-                return load_f32((const float*)Bop + (long long)b * N2p + n);
+                return load8f_if((const float*)Bop + (long long)b * N2p + n, (const float*)Bop, ok2);
             } else {
                 const int d = n >= Hp ? 1 : 0;
-                const int ts = d ? 0 : lens[b] - 1;
-                return *(const u32x4*)((const bf16raw*)Bop + (((long long)ts * B + b) * 2 + d) * Hp + (n - d * Hp));
+                const int ts = d ? 0 : lens[ok2 ? b : 0] - 1;
+                return load16_if((const bf16raw*)Bop + (((long long)ts * B + b) * 2 + d) * Hp + (n - d * Hp), Bop, ok2);
             }
         },
         acc, As, Bs);

@@ -138,6 +138,8 @@ enum sad_ws_field {
     SAD_WS_DL,       /* fp32 [B][L]  dlogits as used by the backward */
     SAD_WS_DWA,      /* fp32 [B][Hp] per-sentence d linear_attn.weight */
     SAD_WS_DSSUM,    /* fp32 [B]     per-sentence d linear_attn.bias */
+    SAD_WS_ROWS,     /* int32 [3][T*B] compacted lists of contributing token rows (weight gradients) */
+    SAD_WS_NROWS,    /* int32 [4]    their lengths */
     SAD_WS_NFIELDS
 };
 

@@ -89,6 +89,8 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_DL] = B * s.L * 4;
     w.bytes[SAD_WS_DWA] = B * s.Hp * 4;
     w.bytes[SAD_WS_DSSUM] = B * 4;
+    w.bytes[SAD_WS_ROWS] = M * 3 * 4;
+    w.bytes[SAD_WS_NROWS] = 4 * 4;
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -223,6 +225,16 @@ int run_prep(const Shape& s, const WsLayout& wl, void* ws, const int32_t* length
                        at<unsigned char>(ws, wl.off[SAD_WS_NEED]), at<int>(ws, wl.off[SAD_WS_LENS]));
     SAD_CHECK_LAUNCH("k_prep");
     return 0;
+}
+
+// Weight-gradient kernels use two LDS tile buffers (up to 120 KB): dynamic LDS above the 64 KB
+// static limit has to be allowed once per kernel.
+template <class W, class K, class... Args>
+void launch_wg(K kernel, dim3 grid, hipStream_t st, Args... args) {
+    static const hipError_t attr =
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES);
+    (void)attr;
+    hipLaunchKernelGGL(kernel, grid, dim3(W::NT), W::LDS_BYTES, st, args...);
 }
 
 template <typename OutT>
@@ -568,15 +580,18 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     const float* DWA = at<float>(ws, wl.off[SAD_WS_DWA]);
     const float* DSSUM = at<float>(ws, wl.off[SAD_WS_DSSUM]);
 
-    // Row splits: ~2 workgroups per CU (every split costs one atomic add per output element), whole
-    // 64-row stages per split.
-    auto row_split = [](int rows, int tiles, int* chunk) {
+    // Compacted lists of the contributing token rows (padding rows are never touched).
+    int* rows = at<int>(ws, wl.off[SAD_WS_ROWS]);
+    int* nrows = at<int>(ws, wl.off[SAD_WS_NROWS]);
+    hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(s.M, 1024)), dim3(256), 0, st, s, need, rows, nrows);
+    SAD_CHECK_LAUNCH("k_row_lists");
+    // Row splits: ~2 workgroups per CU (every split costs one atomic add per output element).  The
+    // list lengths live on the device, so the split is sized for the worst case (every row active).
+    auto row_split = [](int rows_max, int tiles) {
         int want = ceil_div(512, tiles < 1 ? 1 : tiles);
-        const int stages = ceil_div(rows, 64);
+        const int stages = ceil_div(rows_max, 64);
         if (want > stages) want = stages;
-        if (want < 1) want = 1;
-        *chunk = ceil_div(stages, want) * 64;
-        return ceil_div(rows, *chunk);
+        return want < 1 ? 1 : want;
     };
 
     // d embedding.weight
@@ -591,27 +606,26 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
                                (long long)sT, DX, need, pad_id, g->embedding_weight);
         } else if (src_kind == SAD_SRC_F32 || src_kind == SAD_SRC_BF16) {
             if (check_aligned(src, src_kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
-            int chunk;
             if (s.Ep == 320) {          // one n2 tile: S is read exactly once
-                typedef WCfg<128, 320, 2, 4> W;
+                typedef WCfg<64, 320, 2, 4> W;
                 const int t1 = ceil_div(s.V, W::BN1);
-                const int zs = row_split(s.M, t1, &chunk);
+                const dim3 grid(t1, 1, row_split(s.M, t1));
                 if (src_kind == SAD_SRC_F32)
-                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_F32>), dim3(t1, 1, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
-                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+                    launch_wg<W>(k_wgrad_emb<W, SRC_F32>, grid, st, s, src, (long long)sT, (long long)sB, DX, rows, nrows,
+                                 g->embedding_weight);
                 else
-                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_BF16>), dim3(t1, 1, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
-                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+                    launch_wg<W>(k_wgrad_emb<W, SRC_BF16>, grid, st, s, src, (long long)sT, (long long)sB, DX, rows, nrows,
+                                 g->embedding_weight);
             } else {
                 typedef WCfg<128, 64, 4, 1> W;
                 const int t1 = ceil_div(s.V, W::BN1), t2 = ceil_div(s.Ep, W::BN2);
-                const int zs = row_split(s.M, t1 * t2, &chunk);
+                const dim3 grid(t1, t2, row_split(s.M, t1 * t2));
                 if (src_kind == SAD_SRC_F32)
-                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_F32>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
-                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+                    launch_wg<W>(k_wgrad_emb<W, SRC_F32>, grid, st, s, src, (long long)sT, (long long)sB, DX, rows, nrows,
+                                 g->embedding_weight);
                 else
-                    hipLaunchKernelGGL((k_wgrad_emb<W, SRC_BF16>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, src, (long long)sT,
-                                       (long long)sB, DX, need, chunk, g->embedding_weight);
+                    launch_wg<W>(k_wgrad_emb<W, SRC_BF16>, grid, st, s, src, (long long)sT, (long long)sB, DX, rows, nrows,
+                                 g->embedding_weight);
             }
         } else {
             return fail(-1, "unknown src_kind %d", src_kind);
@@ -620,30 +634,25 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     }
     // d rnn.weight_ih (both directions), d linear_emb.weight
     if (g->rnn_weight_ih[0] != nullptr || g->rnn_weight_ih[1] != nullptr || g->linear_emb_weight != nullptr) {
-        int chunk;
         if (s.Ep == 320) {
-            typedef WCfg<128, 320, 2, 4> W;
+            typedef WCfg<64, 320, 2, 4> W;
             const int t1 = ceil_div(s.Ncat, W::BN1);
-            const int zs = row_split(s.M, t1, &chunk);
-            hipLaunchKernelGGL((k_wgrad_cat<W>), dim3(t1, 1, zs), dim3(W::NT), 0, st, s, DZ, X, need, chunk,
-                               g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight);
+            launch_wg<W>(k_wgrad_cat<W>, dim3(t1, 1, row_split(s.M, t1)), st, s, DZ, X, rows, nrows, g->rnn_weight_ih[0],
+                         g->rnn_weight_ih[1], g->linear_emb_weight);
         } else {
             typedef WCfg<128, 64, 4, 1> W;
             const int t1 = ceil_div(s.Ncat, W::BN1), t2 = ceil_div(s.Ep, W::BN2);
-            const int zs = row_split(s.M, t1 * t2, &chunk);
-            hipLaunchKernelGGL((k_wgrad_cat<W>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, DZ, X, need, chunk,
-                               g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight);
+            launch_wg<W>(k_wgrad_cat<W>, dim3(t1, t2, row_split(s.M, t1 * t2)), st, s, DZ, X, rows, nrows,
+                         g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight);
         }
         SAD_CHECK_LAUNCH("k_wgrad_cat");
     }
     // d rnn.weight_hh (both directions)
     if (g->rnn_weight_hh[0] != nullptr || g->rnn_weight_hh[1] != nullptr) {
-        typedef WCfg<128, 128, 2, 2> W;
+        typedef WCfg<128, 256, 2, 4> W;
         const int t1 = ceil_div(s.Gp, W::BN1), t2 = ceil_div(s.Hp, W::BN2);
-        int chunk;
-        const int zs = row_split(s.M, 2 * t1 * t2, &chunk);
-        hipLaunchKernelGGL((k_wgrad_hh<W>), dim3(t1, t2, 2 * zs), dim3(W::NT), 0, st, s, DZ, Hs, need, chunk,
-                           g->rnn_weight_hh[0], g->rnn_weight_hh[1]);
+        launch_wg<W>(k_wgrad_hh<W>, dim3(t1, t2, 2 * row_split(s.M, 2 * t1 * t2)), st, s, DZ, Hs, rows, nrows,
+                     g->rnn_weight_hh[0], g->rnn_weight_hh[1]);
         SAD_CHECK_LAUNCH("k_wgrad_hh");
     }
     // LSTM biases and linear_emb.bias: column sums of DZ
@@ -660,18 +669,15 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     // per-sentence dense layers
     {
         typedef WCfg<64, 64, 2, 2> W;
-        int chunk;
         if (g->hidden_bridge0_weight != nullptr) {
             const int t1 = ceil_div(s.Hp, W::BN1), t2 = ceil_div(2 * s.Hp, W::BN2);
-            const int zs = row_split(s.B, t1 * t2, &chunk);
-            hipLaunchKernelGGL((k_wgrad_dense<W, 1>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, DQ, (const void*)Hs, 2 * s.Hp,
-                               lens, chunk, g->hidden_bridge0_weight);
+            launch_wg<W>(k_wgrad_dense<W, 1>, dim3(t1, t2, row_split(s.B, t1 * t2)), st, s, DQ, (const void*)Hs, 2 * s.Hp,
+                         lens, g->hidden_bridge0_weight);
         }
         if (g->linear_q_weight != nullptr) {
             const int t1 = ceil_div(s.Hp, W::BN1), t2 = ceil_div(s.Hp, W::BN2);
-            const int zs = row_split(s.B, t1 * t2, &chunk);
-            hipLaunchKernelGGL((k_wgrad_dense<W, 0>), dim3(t1, t2, zs), dim3(W::NT), 0, st, s, DU, (const void*)Q, s.Hp, lens,
-                               chunk, g->linear_q_weight);
+            launch_wg<W>(k_wgrad_dense<W, 0>, dim3(t1, t2, row_split(s.B, t1 * t2)), st, s, DU, (const void*)Q, s.Hp, lens,
+                         g->linear_q_weight);
         }
         SAD_CHECK_LAUNCH("k_wgrad_dense");
     }

@@ -26,10 +26,10 @@ namespace sad {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int BN1_, int BN2_, int W1_, int W2_, int NS_ = 2>
+template <int BN1_, int BN2_, int W1_, int W2_>
 struct WCfg {
     static constexpr int BN1 = BN1_, BN2 = BN2_, W1 = W1_, W2 = W2_, BK = 64;
-    static constexpr int NS = NS_;                                 // 64-row tiles of global loads in flight
+    static constexpr int LDS_BYTES = 2 * BK * (BN1_ * 2 + 32 + BN2_ * 2 + 32);   // two tile buffers
     static constexpr int NT = 64 * W1_ * W2_;
     static constexpr int T1 = BN1_ / W1_ / 16, T2 = BN2_ / W2_ / 16;
     static constexpr int P1 = BN1_ * 2 + 32, P2 = BN2_ * 2 + 32;   // LDS row pitch, bytes
@@ -48,64 +48,69 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int pitch) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// row_ok(m) -> bool : token row m (always in [m_begin, m_end)) contributes; may read memory, must be
-//                     BRANCH-FREE (clamp indices instead of guarding the load)
-// load_a(m, c, ok) / load_b(m, c, ok) -> u32x4 : 8 bf16 of columns [c, c+8) of the block tile, row m;
-//                     zeros when !ok; must be BRANCH-FREE (load from a dummy address, then select)
+// The reduction runs over a COMPACTED list of contributing token rows (k_row_lists): 45 % of the
+// rows of a ragged batch are padding and are never touched, and every 64-row tile is full, so the
+// loop has no predicates and no control flow.
+//
+// row_of(j) -> int      : token row of list position j (j already clamped into the list); a memory
+//                         read whose value is not looked at until two tiles later (latency hidden)
+// load_a(row, c, ok) / load_b(row, c, ok) -> u32x4 : 8 bf16 of columns [c, c+8) of the block tile;
+//                         zeros when !ok; BRANCH-FREE (load from a dummy address, then select)
 // acc[t1][t2][e]: dW[n1 = w1*(BN1/W1) + 16*t1 + 4*(lane>>4) + e][n2 = w2*(BN2/W2) + 16*t2 + (lane&15)]
 // (plain operand order: 16 lanes hold 16 CONSECUTIVE n2 of one row -> 64-byte atomic segments).
 //
-// Pipeline: NS tiles of operand loads (register ring, statically indexed) and the row predicates of
-// the two tiles after them are in flight while a tile is multiplied.  Everything in the loop issues
-// a STATIC number of memory operations, so hipcc keeps counted s_waitcnt vmcnt(N) and only the
-// oldest tile is waited for (any control flow around a load makes it drain the whole ring).
-template <class W, class OK, class LA, class LB>
-__device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA load_a, LB load_b,
-                                           f32x4 (&acc)[W::T1][W::T2], unsigned char* As, unsigned char* Bs) {
+// Pipeline (tile = 64 list positions):
+//   * two register slots hold the operand loads of tiles k+1 / k+2 (later k+3); the row-index reads
+//     of the two tiles after those are in flight as well;
+//   * two LDS buffers: while tile k is multiplied out of buffer k&1, tile k+1 is written into the
+//     other one: ONE barrier per tile, and loads / LDS writes / MFMAs of a step share one basic
+//     block, so the scheduler interleaves them;
+//   * the loop issues a STATIC number of memory operations, so hipcc keeps counted
+//     s_waitcnt vmcnt(N) and only the oldest tile is waited for.
+// lds: W::LDS_BYTES = 2 * 64 * (P1 + P2) bytes, 16-byte aligned.
+template <class W, class RO, class LA, class LB>
+__device__ __forceinline__ void wgrad_core(int j_begin, int j_end, RO row_of, LA load_a, LB load_b,
+                                           f32x4 (&acc)[W::T1][W::T2], unsigned char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w1 = wave / W::W2, w2 = wave % W::W2;
-    constexpr int NS = W::NS;
-    u32x4 ra[NS][W::CH1], rb[NS][W::CH2];
-    unsigned fl[NS];                          // predicate bits of the tile held by each ring slot
-    const int nk = (m_end - m_begin + W::BK - 1) / W::BK;
-    auto flags = [&](int kt) {                // bit i: chunk i of this thread sits on a contributing row
-        const int m0 = m_begin + kt * W::BK;
-        unsigned f = 0;
+    constexpr int ABYTES = W::BK * W::P1, BBYTES = W::BK * W::P2, BUF = ABYTES + BBYTES;
+    u32x4 ra[2][W::CH1], rb[2][W::CH2];
+    struct Rows {
+        int v[W::CH1 + W::CH2];
+    };
+    auto rows_of = [&](int kt) {              // issue the row-index reads of tile kt (values unused here)
+        const int j0 = j_begin + kt * W::BK;
+        Rows p;
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
-            const int m = m0 + (tid + i * W::NT) / W::CPR1;
-            const bool ok = row_ok(m < m_end ? m : m_end - 1) && m < m_end;
-            f |= ok ? 1u << i : 0u;
+            const int j = j0 + (tid + i * W::NT) / W::CPR1;
+            p.v[i] = row_of(j < j_end ? j : j_end - 1);
         }
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
-            const int m = m0 + (tid + i * W::NT) / W::CPR2;
-            const bool ok = row_ok(m < m_end ? m : m_end - 1) && m < m_end;
-            f |= ok ? 1u << (W::CH1 + i) : 0u;
+            const int j = j0 + (tid + i * W::NT) / W::CPR2;
+            p.v[W::CH1 + i] = row_of(j < j_end ? j : j_end - 1);
         }
-        return kt < nk ? f : 0u;
+        return p;
     };
-    auto issue = [&](auto slot, int kt, unsigned f) {
+    auto issue = [&](auto slot, int kt, const Rows& p) {
         constexpr int sl = decltype(slot)::value;
-        const int m0 = m_begin + kt * W::BK;
-        fl[sl] = f;
+        const int j0 = j_begin + kt * W::BK;
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1;
-            ra[sl][i] = load_a(m0 + r, c * 8, (f >> i) & 1u);
+            ra[sl][i] = load_a(p.v[i], c * 8, j0 + r < j_end);
         }
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
-            rb[sl][i] = load_b(m0 + r, c * 8, (f >> (W::CH1 + i)) & 1u);
+            rb[sl][i] = load_b(p.v[W::CH1 + i], c * 8, j0 + r < j_end);
         }
     };
-    const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
-    const unsigned char* abase = As + rowsel * W::P1 + (w1 * (W::BN1 / W::W1) + p4) * 2;
-    const unsigned char* bbase = Bs + rowsel * W::P2 + (w2 * (W::BN2 / W::W2) + p4) * 2;
-    auto consume = [&](auto slot) {            // ring slot -> LDS -> MFMAs
+    auto to_lds = [&](auto slot) {             // register slot s -> LDS buffer s
         constexpr int sl = decltype(slot)::value;
-        __syncthreads();                       // every wave is done reading the previous tile
+        unsigned char* As = lds + sl * BUF;
+        unsigned char* Bs = As + ABYTES;
 #pragma unroll
         for (int i = 0; i < W::CH1; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR1, c = g - r * W::CPR1;
@@ -116,9 +121,13 @@ __device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA
             const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
             *(u32x4*)(Bs + r * W::P2 + c * 16) = rb[sl][i];
         }
-        return __syncthreads_or(fl[sl] != 0u);
     };
-    auto mfma_tile = [&]() {
+    const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
+    const int aoff = rowsel * W::P1 + (w1 * (W::BN1 / W::W1) + p4) * 2;
+    const int boff = ABYTES + rowsel * W::P2 + (w2 * (W::BN2 / W::W2) + p4) * 2;
+    auto mfma_tile = [&](auto buf) {
+        const unsigned char* abase = lds + decltype(buf)::value * BUF + aoff;
+        const unsigned char* bbase = lds + decltype(buf)::value * BUF + boff;
 #pragma unroll
         for (int ks = 0; ks < W::BK / 32; ++ks) {
             bf16x8 fa[W::T1], fb[W::T2];
@@ -133,23 +142,44 @@ __device__ __forceinline__ void wgrad_core(int m_begin, int m_end, OK row_ok, LA
                     acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t1], fb[t2], acc[t1][t2], 0, 0, 0);
         }
     };
-    // Prologue: predicates of the first NS+2 tiles, then NS tiles of loads (tiles past the end have
-    // all-zero predicates: their loads hit the dummy address and return zeros).
-    unsigned f0 = 0, f1 = 0;                   // predicates of the next two tiles to be issued
-    static_for<NS>([&](auto slot) { issue(slot, decltype(slot)::value, flags(decltype(slot)::value)); });
-    f0 = flags(NS);
-    f1 = flags(NS + 1);
-    const int groups = (nk + NS - 1) / NS;
-    for (int gk = 0; gk < groups; ++gk) {
-        static_for<NS>([&](auto slot) {
-            const int kt = gk * NS + decltype(slot)::value;
-            const int any = consume(slot);
-            issue(slot, kt + NS, f0);          // refill this slot (zeros past the end)
-            f0 = f1;
-            f1 = flags(kt + NS + 2);
-            if (any) mfma_tile();              // block-uniform: EXEC stays full for the transposed reads
-        });
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nk = (j_end - j_begin + W::BK - 1) / W::BK;
+    // Prologue.  Tiles past the end load nothing (ok = false: dummy address, zeros), so the loop
+    // body needs no tail case.
+    issue(S0{}, 0, rows_of(0));
+    issue(S1{}, 1, rows_of(1));
+    Rows p0 = rows_of(2), p1 = rows_of(3);
+    to_lds(S0{});
+    issue(S0{}, 2, p0);
+    p0 = p1;
+    p1 = rows_of(4);
+    __syncthreads();
+    // Tile k is multiplied out of buffer k&1 while tile k+1 moves from slot (k+1)&1 into the other
+    // buffer and that slot is refilled with tile k+3.
+    auto step = [&](auto par, int k) {
+        constexpr int P = decltype(par)::value, Q = P ^ 1;
+        to_lds(std::integral_constant<int, Q>{});
+        issue(std::integral_constant<int, Q>{}, k + 3, p0);
+        p0 = p1;
+        p1 = rows_of(k + 5);
+        mfma_tile(std::integral_constant<int, P>{});
+        __syncthreads();
+    };
+    for (int k = 0; k < nk; k += 2) {
+        step(S0{}, k);
+        step(S1{}, k + 1);
     }
+}
+
+// This workgroup's slice [j_begin, j_end) of a row list of `count` entries split `zs` ways in whole
+// 64-row tiles.  False: nothing to do.
+__device__ __forceinline__ bool wgrad_slice(int count, int z, int zs, int* j_begin, int* j_end) {
+    const int tiles = (count + 63) / 64;
+    const int per = (tiles + zs - 1) / zs * 64;
+    *j_begin = z * per;
+    *j_end = min(count, *j_begin + per);
+    return *j_begin < *j_end;
 }
 
 // Branch-free 16-byte load: `ok ? *p : 0`, reading `dummy` instead when !ok.
@@ -195,6 +225,125 @@ __device__ __forceinline__ void atomic_add4(float* dst, int col, int limit, f32x
         if (col + e < limit) unsafeAtomicAdd(dst + e, v[e]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compacted lists of the token rows that contribute to a weight gradient, ascending, from the need
+// bits:  list 0: need != 0 (embedding / input-projection / linear_emb gradients);
+//        list 1: t >= 1 and t < len      (forward-direction  W_hh: rows that have an h_{t-1});
+//        list 2: t + 1 < len             (reverse-direction  W_hh: rows that have an h_{t+1}).
+// rows: int32 [3][M], nrows: int32 [3].  One 1024-thread workgroup (M is a few 10^4..10^5).
+// ------------------------------------------------------------------------------------------------
+enum { ROWS_ANY = 0, ROWS_FWD = 1, ROWS_REV = 2 };
+// Each 256-thread workgroup compacts one 1024-row segment.  Its output offsets are the counts over
+// all earlier rows, which it recounts itself from the need bytes (a few 10 KB, L2-resident) instead
+// of waiting for its predecessors:  with C1(x) = #{m < x : bit0}, Cany(x) = #{m < x : need != 0},
+//   offset_any = Cany(m0),  offset_fwd = C1(m0) - C1(min(B, m0)),  offset_rev = C1(min(M, m0+B)) - C1(min(M, B)).
+__global__ __launch_bounds__(256) void k_row_lists(Shape s, const unsigned char* __restrict__ need, int* __restrict__ rows,
+                                                  int* __restrict__ nrows) {
+    __shared__ int red[4][4];
+    __shared__ int wsum[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = s.M, B = s.B;
+    const int m0 = blockIdx.x * 1024;
+    const bool last = m0 + 1024 >= M;
+    // limits: [0] Cany(m0)  [1] C1(m0)  [2] C1(min(B, M))  [3] C1(min(M, m0 + B));  the last segment
+    // also produces the totals, so it counts up to M instead of m0.
+    const int mend = last ? M : m0;
+    const int lim[4] = {mend, mend, min(B, M), min(M, mend + B)};
+    int cnt[4] = {0, 0, 0, 0};
+    const int scan_to = lim[3] > lim[0] ? lim[3] : lim[0];
+    for (int c = tid * 16; c < scan_to; c += 256 * 16) {
+        const u32x4 w = *(const u32x4*)(need + c);            // need is padded to a multiple of 256 bytes
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int base = c + 4 * q;
+            const unsigned anyb = (w[q] | (w[q] >> 1)) & 0x01010101u, b0 = w[q] & 0x01010101u;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const unsigned bits = l == 0 ? anyb : b0;
+                const int left = lim[l] - base;               // rows of this dword below the limit
+                const unsigned m = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+                cnt[l] += __popc(bits & m);
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        int v = cnt[l];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[l][wave] = v;
+    }
+    __syncthreads();
+    int C[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) C[l] = red[l][0] + red[l][1] + red[l][2] + red[l][3];
+    if (last && tid == 0) {
+        nrows[ROWS_ANY] = C[0];
+        nrows[ROWS_FWD] = C[1] - C[2];
+        nrows[ROWS_REV] = C[3] - C[2];                        // rows m with m + B < M and bit0 of need[m + B]
+    }
+    if (last) {                                               // recount this segment's own offsets up to m0
+        __syncthreads();
+        int c2[4] = {0, 0, 0, 0};
+        const int lim2[4] = {m0, m0, min(B, M), min(M, m0 + B)};
+        for (int c = tid * 16; c < lim2[3] || c < lim2[0]; c += 256 * 16) {
+            const u32x4 w = *(const u32x4*)(need + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int base = c + 4 * q;
+                const unsigned anyb = (w[q] | (w[q] >> 1)) & 0x01010101u, b0 = w[q] & 0x01010101u;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    const unsigned bits = l == 0 ? anyb : b0;
+                    const int left = lim2[l] - base;
+                    const unsigned m = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+                    c2[l] += __popc(bits & m);
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            int v = c2[l];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) red[l][wave] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 4; ++l) C[l] = red[l][0] + red[l][1] + red[l][2] + red[l][3];
+    }
+    const int off[3] = {C[0], m0 >= B ? C[1] - C[2] : 0, C[3] - C[2]};
+    // own segment: 4 consecutive rows per thread
+    int flag[3][4], mine[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * tid + i;
+        const int nd = m < M ? need[m] : 0;
+        const int nn = m + B < M ? need[m + B] : 0;
+        flag[ROWS_ANY][i] = nd != 0;
+        flag[ROWS_FWD][i] = m >= B && (nd & 1);
+        flag[ROWS_REV][i] = nn & 1;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) mine[l] += flag[l][i];
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        int incl = mine[l];                                   // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[l][wave] = incl;
+        __syncthreads();
+        int pos = off[l] + incl - mine[l];
+        for (int wv = 0; wv < wave; ++wv) pos += wsum[l][wv];
+        int* out = rows + (long long)l * M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (flag[l][i]) out[pos++] = m0 + 4 * tid + i;
+    }
+}
+
 // Packed (permuted) gate column -> row of a torch [4H, *] LSTM parameter, or -1 for padding.
 __device__ __forceinline__ int gate_row(int pc, int H) {
     const int unit = (pc >> 6) * 16 + (pc & 15), gate = (pc & 63) >> 4;
@@ -209,13 +358,13 @@ __device__ __forceinline__ int gate_row(int pc, int H) {
 template <class W>
 __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __restrict__ DZ,
                                                     const bf16raw* __restrict__ X,
-                                                    const unsigned char* __restrict__ need, int mchunk,
+                                                    const int* __restrict__ rows, const int* __restrict__ nrows,
                                                     float* __restrict__ gih0, float* __restrict__ gih1,
                                                     float* __restrict__ glin) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];   // 2 * 64 * (P1 + P2) bytes
     const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
-    const int m_begin = blockIdx.z * mchunk, m_end = min(s.M, m_begin + mchunk);
+    int j_begin, j_end;
+    if (!wgrad_slice(nrows[ROWS_ANY], blockIdx.z, gridDim.z, &j_begin, &j_end)) return;
     const int Ncat = s.Ncat, Ep = s.Ep;
     // skip column blocks whose destination is absent (frozen tensors)
     {
@@ -227,7 +376,7 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
     wgrad_core<W>(
-        m_begin, m_end, [&](int m) { return need[m] != 0; },
+        j_begin, j_end, [&](int j) { return rows[j]; },
         [&](int m, int c, bool ok) {
             const int n = n10 + c;
             return load16_if(DZ + (long long)m * Ncat + n, DZ, ok && n < Ncat);
@@ -236,7 +385,7 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
             const int n = n20 + c;
             return load16_if(X + (long long)m * Ep + n, X, ok && n < Ep);
         },
-        acc, As, Bs);
+        acc, wg_lds);
     const int E = s.E, H = s.H, Gp = s.Gp;
     wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
@@ -263,25 +412,22 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
 template <class W>
 __global__ __launch_bounds__(W::NT) void k_wgrad_hh(Shape s, const bf16raw* __restrict__ DZ,
                                                    const bf16raw* __restrict__ Hs,
-                                                   const unsigned char* __restrict__ need, int mchunk,
+                                                   const int* __restrict__ rows, const int* __restrict__ nrows,
                                                    float* __restrict__ ghh0, float* __restrict__ ghh1) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];   // 2 * 64 * (P1 + P2) bytes
     const int dir = blockIdx.z & 1;
     float* g = dir ? ghh1 : ghh0;
     if (g == nullptr) return;
     const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
-    const int m_begin = (blockIdx.z >> 1) * mchunk, m_end = min(s.M, m_begin + mchunk);
-    const int Ncat = s.Ncat, Hp = s.Hp, Gp = s.Gp, B = s.B, M = s.M;
+    int j_begin, j_end;
+    if (!wgrad_slice(nrows[ROWS_FWD + dir], blockIdx.z >> 1, gridDim.z >> 1, &j_begin, &j_end)) return;
+    const int* list = rows + (long long)(ROWS_FWD + dir) * s.M;
+    const int Ncat = s.Ncat, Hp = s.Hp, Gp = s.Gp, B = s.B;
     const long long shift = dir ? B : -B;         // token-row offset of the previous recurrence step
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
     wgrad_core<W>(
-        m_begin, m_end,
-        [&](int m) {
-            const bool inr = dir ? (m + B < M) : (m >= B);
-            return inr && (need[inr && dir ? m + B : m] & 1);
-        },
+        j_begin, j_end, [&](int j) { return list[j]; },
         [&](int m, int c, bool ok) {
             const int n = n10 + c;
             return load16_if(DZ + (long long)m * Ncat + dir * Gp + n, DZ, ok && n < Gp);
@@ -290,7 +436,7 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_hh(Shape s, const bf16raw* __re
             const int n = n20 + c;
             return load16_if(Hs + ((m + shift) * 2 + dir) * Hp + n, Hs, ok && n < Hp);
         },
-        acc, As, Bs);
+        acc, wg_lds);
     const int H = s.H;
     wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
@@ -308,18 +454,18 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_hh(Shape s, const bf16raw* __re
 template <class W, int KIND>
 __global__ __launch_bounds__(W::NT) void k_wgrad_emb(Shape s, const void* __restrict__ src, long long sT, long long sB,
                                                     const bf16raw* __restrict__ DX,
-                                                    const unsigned char* __restrict__ need, int mchunk,
+                                                    const int* __restrict__ rows, const int* __restrict__ nrows,
                                                     float* __restrict__ gemb) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];   // 2 * 64 * (P1 + P2) bytes
     typedef SoftRow<KIND> SR;
     typedef typename SR::Elem Elem;
     const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
-    const int m_begin = blockIdx.z * mchunk, m_end = min(s.M, m_begin + mchunk);
+    int j_begin, j_end;
+    if (!wgrad_slice(nrows[ROWS_ANY], blockIdx.z, gridDim.z, &j_begin, &j_end)) return;
     const int V = s.V, Ep = s.Ep, B = s.B;
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
-    auto row_ok = [&](int m) { return need[m] != 0; };
+    auto row_of = [&](int j) { return rows[j]; };
     auto load_b = [&](int m, int c, bool ok) {
         const int n = n20 + c;
         return load16_if(DX + (long long)m * Ep + n, DX, ok && n < Ep);
@@ -330,16 +476,16 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_emb(Shape s, const void* __rest
     };
     if (n10 + W::BN1 <= V) {     // interior vocabulary tile: whole chunks, branch-free loads
         wgrad_core<W>(
-            m_begin, m_end, row_ok,
+            j_begin, j_end, row_of,
             [&](int m, int c, bool ok) {
                 return typename SR::Cvt()(SR::load_fast(s_row(m, ok), (const Elem*)src, n10 + c));
             },
-            load_b, acc, As, Bs);
+            load_b, acc, wg_lds);
     } else {                     // the tile holding the ragged end of V: element-guarded loads
         wgrad_core<W>(
-            m_begin, m_end, row_ok,
+            j_begin, j_end, row_of,
             [&](int m, int c, bool ok) { return typename SR::Cvt()(SR::load(s_row(m, ok), n10 + c, V)); }, load_b, acc,
-            As, Bs);
+            wg_lds);
     }
     const int E = s.E;
     wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
@@ -376,17 +522,16 @@ __global__ void k_wgrad_emb_ids(Shape s, const long long* __restrict__ ids, long
 // ------------------------------------------------------------------------------------------------
 template <class W, int BKIND>
 __global__ __launch_bounds__(W::NT) void k_wgrad_dense(Shape s, const float* __restrict__ A, const void* __restrict__ Bop,
-                                                      int N2p, const int* __restrict__ lens, int mchunk,
-                                                      float* __restrict__ g) {
-    __shared__ __attribute__((aligned(16))) unsigned char As[64 * W::P1];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * W::P2];
+                                                      int N2p, const int* __restrict__ lens, float* __restrict__ g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];   // 2 * 64 * (P1 + P2) bytes
     const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
-    const int m_begin = blockIdx.z * mchunk, m_end = min(s.B, m_begin + mchunk);
+    int j_begin, j_end;
+    if (!wgrad_slice(s.B, blockIdx.z, gridDim.z, &j_begin, &j_end)) return;
     const int Hp = s.Hp, B = s.B;
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
     wgrad_core<W>(
-        m_begin, m_end, [&](int b) { return BKIND == 0 || lens[b] > 0; },
+        j_begin, j_end, [](int j) { return j; },
         [&](int b, int c, bool ok) {
             const int n = n10 + c;
             return load8f_if(A + (long long)b * Hp + n, A, ok && n < Hp);
@@ -398,11 +543,13 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_dense(Shape s, const float* __r
                 return load8f_if((const float*)Bop + (long long)b * N2p + n, (const float*)Bop, ok2);
             } else {
                 const int d = n >= Hp ? 1 : 0;
-                const int ts = d ? 0 : lens[ok2 ? b : 0] - 1;
-                return load16_if((const bf16raw*)Bop + (((long long)ts * B + b) * 2 + d) * Hp + (n - d * Hp), Bop, ok2);
+                const int len = lens[ok2 ? b : 0];
+                const int ts = d ? 0 : len - 1;
+                return load16_if((const bf16raw*)Bop + (((long long)ts * B + b) * 2 + d) * Hp + (n - d * Hp), Bop,
+                                 ok2 && len > 0);
             }
         },
-        acc, As, Bs);
+        acc, wg_lds);
     const int H = s.H;
     wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;

@@ -140,6 +140,8 @@ enum sad_ws_field {
     SAD_WS_DSSUM,    /* fp32 [B]     per-sentence d linear_attn.bias */
     SAD_WS_ROWS,     /* int32 [3][T*B] compacted lists of contributing token rows (weight gradients) */
     SAD_WS_NROWS,    /* int32 [4]    their lengths */
+    SAD_WS_SYNC,     /* u32: hand-off counters of the persistent recurrence (one 128-B line per sentence
+                        tile and direction), then the timeout word (non-zero = a wait timed out) */
     SAD_WS_NFIELDS
 };
 

@@ -3,6 +3,7 @@
 #include "../../include/sad.h"
 #include "kernels.hpp"
 #include "wgrad.hpp"
+#include "lstm_persist.hpp"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -91,6 +92,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_DSSUM] = B * 4;
     w.bytes[SAD_WS_ROWS] = M * 3 * 4;
     w.bytes[SAD_WS_NROWS] = 4 * 4;
+    w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -235,6 +237,24 @@ void launch_wg(K kernel, dim3 grid, hipStream_t st, Args... args) {
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES);
     (void)attr;
     hipLaunchKernelGGL(kernel, grid, dim3(W::NT), W::LDS_BYTES, st, args...);
+}
+
+// The persistent recurrence needs every workgroup co-resident (they wait for each other): the grid
+// must fit the device at the kernel's own occupancy.  SAD_NO_PERSIST=1 forces the per-step kernels.
+bool lstm_persist_fits(const Shape& s, int* grid) {
+    static const bool off = getenv("SAD_NO_PERSIST") != nullptr && atoi(getenv("SAD_NO_PERSIST")) != 0;
+    if (off || s.Hp > 64 * LP_KT_MAX || s.Gp % LP_BN != 0) return false;
+    const size_t lds = lstm_persist_lds_bytes(s.Hp);
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k_lstm_fwd_persist,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_lstm_fwd_persist, 512, lds) != hipSuccess)
+        return false;
+    *grid = 2 * ceil_div(s.B, LP_BM) * (s.Gp / LP_BN);
+    return per_cu >= 1 && *grid <= per_cu * cus;
 }
 
 template <typename OutT>
@@ -427,17 +447,25 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
         SAD_CHECK_LAUNCH("k_inproj_fwd");
     }
 
-    // K2b: T dependent steps, both directions per launch
-    static const int dbg = getenv("SAD_DBG") ? atoi(getenv("SAD_DBG")) : 0;   // timing diagnostics only
-    for (int step = 0; step < s.T; ++step) {
-        if (s.B >= 512) {
-            typedef CfgStepBig C;
-            dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
-            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, dbg);
-        } else {
-            typedef CfgStepSmall C;
-            dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
-            hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, dbg);
+    // K2b: the recurrence.  Persistent weight-stationary kernel (one launch for all T steps) when its
+    // grid is co-resident, else T dependent launches (both directions per launch).
+    int pgrid = 0;
+    if (lstm_persist_fits(s, &pgrid)) {
+        unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
+        (void)hipMemsetAsync(sync, 0, wl.bytes[SAD_WS_SYNC], st);
+        hipLaunchKernelGGL(k_lstm_fwd_persist, dim3(pgrid), dim3(512), lstm_persist_lds_bytes(s.Hp), st, s, lens,
+                           at<bf16raw>(packed, pl.whh), G, Cs, Hs, sync);
+    } else {
+        for (int step = 0; step < s.T; ++step) {
+            if (s.B >= 512) {
+                typedef CfgStepBig C;
+                dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
+                hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, 0);
+            } else {
+                typedef CfgStepSmall C;
+                dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
+                hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, 0);
+            }
         }
     }
     SAD_CHECK_LAUNCH("k_lstm_fwd");

@@ -101,6 +101,8 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
         if param_grads:
             out["grads"] = {k: (None if v.grad is None else v.grad.cpu().numpy()) for k, v in live.items()}
     torch.cuda.synchronize()
+    # hand-off counters of the persistent recurrence: the word after them is set when a wait timed out
+    assert int(ws.view("SYNC", torch.int32)[-32]) == 0, "persistent LSTM: a hand-off wait timed out"
     out.update(logits=logits.detach().cpu().numpy(), weights=weights.detach().cpu().numpy(),
                loss=None if loss is None else loss.detach().cpu().numpy(), mask_after=m.cpu().numpy())
     if want_ws:

@@ -242,7 +242,8 @@ void launch_wg(K kernel, dim3 grid, hipStream_t st, Args... args) {
 // The persistent recurrence needs every workgroup co-resident (they wait for each other): the grid
 // must fit the device at the kernel's own occupancy.  SAD_NO_PERSIST=1 forces the per-step kernels.
 bool lstm_persist_fits(const Shape& s, int* grid) {
-    static const bool off = getenv("SAD_NO_PERSIST") != nullptr && atoi(getenv("SAD_NO_PERSIST")) != 0;
+    const char* env = getenv("SAD_NO_PERSIST");      // read per call: tests switch paths in-process
+    const bool off = env != nullptr && atoi(env) != 0;
     if (off || s.Hp > 64 * LP_KT_MAX || s.Gp % LP_BN != 0) return false;
     const size_t lds = lstm_persist_lds_bytes(s.Hp);
     int dev = 0, cus = 0, per_cu = 0;
@@ -450,9 +451,9 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
     // K2b: the recurrence.  Persistent weight-stationary kernel (one launch for all T steps) when its
     // grid is co-resident, else T dependent launches (both directions per launch).
     int pgrid = 0;
+    unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
+    (void)hipMemsetAsync(sync, 0, wl.bytes[SAD_WS_SYNC], st);   // counters + timeout word, every call
     if (lstm_persist_fits(s, &pgrid)) {
-        unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
-        (void)hipMemsetAsync(sync, 0, wl.bytes[SAD_WS_SYNC], st);
         hipLaunchKernelGGL(k_lstm_fwd_persist, dim3(pgrid), dim3(512), lstm_persist_lds_bytes(s.Hp), st, s, lens,
                            at<bf16raw>(packed, pl.whh), G, Cs, Hs, sync);
     } else {

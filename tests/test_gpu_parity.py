@@ -406,6 +406,59 @@ def test_full_batch_bit_exact_properties():
         assert torch.equal(plg, lg[lo:hi]) and torch.equal(pw_, w[lo:hi]) and torch.equal(pdS, dS[lo:hi])
 
 
+def test_persistent_recurrence_matches_per_step_kernels():
+    """The persistent LSTM (in-launch h hand-off between workgroups) against the one-launch-per-step
+    kernels on the same inputs: every hidden state, cell state and output agrees to fp32 rounding, and
+    repeated persistent runs are BIT-identical (a stale hand-off read would show as a difference), at
+    full batch (one workgroup per CU), at a ragged batch (partial sentence tile) and at H not a
+    multiple of 64."""
+    import os
+    import torch
+    from sad_amd import functional as Fn
+    dev = torch.device("cuda:0")
+    for (B, T, V, E, H) in ((1024, 32, 500, 300, 512), (200, 17, 300, 44, 96), (64, 23, 300, 300, 512)):
+        lengths = synth.make_lengths(B, T, seed=B)
+        params = synth.make_params(V, E, H, seed=3)
+        pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})
+        ids = torch.from_numpy(synth.make_token_ids(B, T, V, lengths, seed=5)).to(dev)
+        ln = torch.from_numpy(lengths)
+        mask0 = torch.from_numpy(synth.transfer_mask(lengths, T)).to(dev)
+        lab = torch.from_numpy(synth.make_labels(B, seed=1)).to(dev)
+
+        def run(no_persist):
+            os.environ["SAD_NO_PERSIST"] = "1" if no_persist else "0"
+            try:
+                loss, logits, weights = Fn.discriminator_loss(ids, ln, mask0.clone(), lab, pw)
+                ws = Fn._Discriminator.last_workspace
+                torch.cuda.synchronize()
+                assert int(ws.view("SYNC", torch.int32)[-32]) == 0
+                live = (ws.view("NEED", torch.uint8).reshape(T, B) & 1).bool()      # t < len: rows the LSTM writes
+                hs = ws.view("HS", torch.int16).reshape(T, B, -1)[live]
+                cs = ws.view("CS", torch.int32).reshape(T, B, -1)[live]
+                return logits.clone(), weights.clone(), loss.clone(), hs.clone(), cs.clone()
+            finally:
+                os.environ.pop("SAD_NO_PERSIST", None)
+
+        ref = run(True)
+        first = run(False)
+        # the two paths run the same arithmetic up to the compiler's fma contraction in the cell update:
+        # fp32-ulp differences that grow slowly over the steps (measured 1.7e-4 on c after 32 steps)
+        for a, b, name, tol in zip(first, ref, ("logits", "weights", "loss", "Hs", "Cs"), (1e-4, 1e-4, 1e-4, 0, 2e-3)):
+            if name == "Hs":      # bf16 bit patterns: at most one ulp apart
+                d = (a.view(torch.bfloat16).float() - b.view(torch.bfloat16).float()).abs().max().item()
+                assert d <= 2.0 ** -7, (B, T, H, name, d)
+            elif name == "Cs":
+                d = (a.view(torch.float32) - b.view(torch.float32)).abs().max().item()
+                assert d < tol, (B, T, H, name, d)
+            else:
+                assert (a - b).abs().max().item() < tol, (B, T, H, name)
+        # a stale or torn hand-off read would make the persistent path differ from run to run
+        for rep in range(4):
+            got = run(False)
+            for a, b, name in zip(got, first, ("logits", "weights", "loss", "Hs", "Cs")):
+                assert torch.equal(a, b), (B, T, H, rep, name)
+
+
 def test_ragged_and_edge_shapes():
     """Edge cases: B=1, all lengths equal to T, len==2 rows (all-masked guard), a batch and T that
     are not multiples of any tile size, unsorted lengths given on the device (no host check)."""

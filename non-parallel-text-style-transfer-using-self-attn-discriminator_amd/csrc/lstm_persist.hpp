@@ -34,6 +34,17 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define SAD_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// 16-byte sc1 (L1-bypassing, agent-coherent) load through a buffer descriptor: visible to the
+// compiler's waitcnt pass (counted vmcnt), and an offset beyond `bytes` returns zeros, which serves
+// as a branch-free row predicate.
+constexpr unsigned LP_OOB = 0x7ffffff0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lp_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
+}
+
 constexpr int LP_BM = 128, LP_BN = 128, LP_KT_MAX = 8;       // tile; Hp <= 64 * LP_KT_MAX
 constexpr int LP_SYNC_PITCH = 32;                            // counter pitch in 4-byte words (128-B lines)
 constexpr unsigned LP_SPIN_LIMIT = 1u << 22;
@@ -147,34 +158,25 @@ __global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
             __syncthreads();
-            // ---- all of this tile's h_{tp} in flight at once (sc1 loads, 8 bytes each) ----------------
-            unsigned long long a[LP_KT_MAX][2][2];
+            // ---- all of this tile's h_{tp} in flight at once (16-byte sc1 loads) -----------------------
+            u32x4 a[LP_KT_MAX][2];
+            {
+                const __amdgpu_buffer_rsrc_t rs = lp_rsrc(Hs + (long long)tp * B * 2 * Hp, (unsigned)B * 2u * Hp * 2u);
 #pragma unroll
-            for (int kt = 0; kt < LP_KT_MAX; ++kt)
+                for (int kt = 0; kt < LP_KT_MAX; ++kt)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[kt][i][0] = a[kt][i][1] = 0ull;
-                    const int k = kt * 64 + skc;
-                    if (slen[i] > tp && k < Hp) {
-                        gu64* p = (gu64*)(Hs + (((long long)tp * B + srow[i]) * 2 + dir) * Hp + k);
-                        a[kt][i][0] = __hip_atomic_load(p, SAD_RLX_AGENT);
-                        a[kt][i][1] = __hip_atomic_load(p + 1, SAD_RLX_AGENT);
+                    for (int i = 0; i < 2; ++i) {
+                        const int k = kt * 64 + skc;
+                        const bool ok = slen[i] > tp && k < Hp;
+                        a[kt][i] = lp_load16_sc1(rs, ok ? (unsigned)(((srow[i] - 0) * 2 + dir) * Hp + k) * 2u : LP_OOB);
                     }
-                }
+            }
             // ---- gates += h_{tp} . W_hh^T against the resident slice -----------------------------------
             // k-tile kt+1 is written into the other As buffer while kt is multiplied: one barrier per k-tile.
-            auto stage = [&](int kt, const unsigned long long (&ak)[2][2]) {
+            auto stage = [&](int kt, const u32x4 (&ak)[2]) {
                 bf16raw* buf = As + (kt & 1) * (LP_BM * 64);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r = (tid >> 3) + i * 64;
-                    u32x4 v;
-                    v[0] = (unsigned)ak[i][0];
-                    v[1] = (unsigned)(ak[i][0] >> 32);
-                    v[2] = (unsigned)ak[i][1];
-                    v[3] = (unsigned)(ak[i][1] >> 32);
-                    *(u32x4*)&buf[lds_off<C>(r, skc >> 3)] = v;
-                }
+                for (int i = 0; i < 2; ++i) *(u32x4*)&buf[lds_off<C>((tid >> 3) + i * 64, skc >> 3)] = ak[i];
             };
             __syncthreads();                                 // As free (previous step / prologue done with it)
             stage(0, a[0]);
@@ -246,6 +248,204 @@ __global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __
             *(f32x4*)(g + 48) = go[tm];
             *(f32x4*)&Cs[(((long long)t * B + brow[tm]) * 2 + dir) * Hp + j] = creg[tm];
         }
+    }
+}
+
+}  // namespace sad
+
+namespace sad {
+
+// ------------------------------------------------------------------------------------------------
+// Persistent BPTT (K2'): ONE launch for all T steps of both directions, frozen weights.
+//   dh_t = dZ_{next} . W_hh (+ d h_final at a sentence's last step), gate derivatives -> dZ_t.
+// A workgroup owns 128 sentences x 32 hidden units of one direction; its W_hh^T slice [32][Gp] bf16
+// (128 KB) stays in LDS, dc of its (sentence, unit) pairs stays in registers.  Per step it needs
+// dZ_{next} of its 128 sentences over ALL Gp gate columns (written by the 16 workgroups of its
+// group), 512 KB.  That operand never passes through LDS: wave w owns sentences 16w..16w+15 and
+// loads their fragments straight from global memory (sc1) into registers in MFMA layout, three
+// fragment sets in flight; there is no barrier inside the K loop, no cross-wave reduction (every
+// dh is summed by one wave in a fixed order: results are reproducible bit for bit), and the
+// accumulator layout (lane = sentence, 4 consecutive units) is exactly the epilogue's.
+// Hand-off protocol: as in k_lstm_fwd_persist.
+// ------------------------------------------------------------------------------------------------
+constexpr int LB_BM = 128, LB_BN = 32, LB_SG_MAX = 16;       // Gp <= 128 * LB_SG_MAX
+
+__host__ __device__ inline size_t lstm_bwd_persist_lds_bytes(int Gp) { return (size_t)LB_BN * Gp * 2 + 16; }
+
+__global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __restrict__ lens,
+                                                         const bf16raw* __restrict__ whhT, const float* __restrict__ G,
+                                                         const float* __restrict__ Cs, const float* __restrict__ DHFIN,
+                                                         bf16raw* DZ, unsigned* sync) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
+    const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
+    bf16raw* Wl = (bf16raw*)lp_lds;                                  // [32][Gp], chunk-swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctiles = Hp / LB_BN, rtiles = (B + LB_BM - 1) / LB_BM, groups = rtiles * 2;
+    int group, ct;
+    if (groups % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        group = xcd + 8 * (slot / ctiles);
+        ct = slot % ctiles;
+    } else {
+        group = blockIdx.x / ctiles;
+        ct = blockIdx.x % ctiles;
+    }
+    const int dir = group & 1, b0 = (group >> 1) * LB_BM, j0 = ct * LB_BN;
+    gu32* counter = (gu32*)(sync + (size_t)group * LP_SYNC_PITCH);
+    gu32* errword = (gu32*)(sync + (size_t)groups * LP_SYNC_PITCH + 1);
+    const int cpr = Gp / 8;                                          // 16-byte chunks per W row (multiple of 16)
+
+    // ---- once: W_hh^T slice -> LDS; longest sentence of the tile -----------------------------------
+    {
+        const bf16raw* w = whhT + ((long long)dir * Hp + j0) * Gp;
+        for (int idx = tid; idx < LB_BN * cpr; idx += 512) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            *(u32x4*)(Wl + (long long)r * Gp + lp_wswz(r, c, 15) * 8) = *(const u32x4*)(w + (long long)r * Gp + c * 8);
+        }
+    }
+    int maxlen = 0;
+    {
+        int* red_max = (int*)(lp_lds + (size_t)LB_BN * Gp * 2);
+        if (tid == 0) *red_max = 0;
+        __syncthreads();
+        if (tid < LB_BM && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
+        __syncthreads();
+        maxlen = *red_max;
+    }
+    // this lane: sentence b0 + 16*wave + (lane & 15); unit quads j0 + 16*tn + 4*(lane >> 4), tn = 0, 1
+    const int b = b0 + wave * 16 + (lane & 15);
+    const int len = b < B ? lens[b] : 0;
+    int ju[2], pcu[2];
+    f32x4 dcreg[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        ju[tn] = j0 + 16 * tn + 4 * (lane >> 4);
+        pcu[tn] = (ju[tn] >> 4) * 64 + (ju[tn] & 15);
+        dcreg[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // dZ rows of padded steps (t >= len) are exact zeros: later kernels read every row of DZ.
+    if (b < B) {
+        for (int t = len; t < T; ++t) {
+            bf16raw* zrow = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(u32x2*)&zrow[pcu[tn] + g * 16] = u32x2{0u, 0u};
+        }
+    }
+    const int nsg = Gp / 128;                                // fragment sets of 4 x 32 k
+    unsigned done = 0;
+    bool dead = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? step : T - 1 - step;             // reverse of the forward order
+        if (!(maxlen > t)) continue;                         // group-uniform
+        const int tn_ = dir ? t - 1 : t + 1;                 // step whose dZ feeds dh_t
+        const int tpf = dir ? t + 1 : t - 1;                 // forward-previous step (source of c_prev)
+        const bool act = len > t;
+        // epilogue operands: private to the workgroup, independent of the hand-off -> issued first
+        f32x4 egi[2], egf[2], egg[2], ego[2], ec[2], ecp[2], edhf[2];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            egi[tn] = egf[tn] = egg[tn] = ego[tn] = ec[tn] = ecp[tn] = edhf[tn] = z;
+            if (!act) continue;
+            const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + pcu[tn];
+            egi[tn] = *(const f32x4*)(g + 0);
+            egf[tn] = *(const f32x4*)(g + 16);
+            egg[tn] = *(const f32x4*)(g + 32);
+            ego[tn] = *(const f32x4*)(g + 48);
+            ec[tn] = *(const f32x4*)&Cs[(((long long)t * B + b) * 2 + dir) * Hp + ju[tn]];
+            if (tpf >= 0 && tpf < T && len > tpf) ecp[tn] = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + ju[tn]];
+            const bool last = dir ? (t == 0) : (t == len - 1);
+            if (last) edhf[tn] = *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + ju[tn]];
+        }
+        f32x4 acc[2];
+        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (done > 0) {
+            if (tid == 0 && !dead) {
+                const unsigned target = done * (unsigned)ctiles;
+                unsigned spins = 0;
+                while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > LP_SPIN_LIMIT) {
+                        __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
+                        dead = true;
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __syncthreads();
+            // ---- dh = dZ_{tn} . W_hh for this wave's 16 sentences ------------------------------------
+            const bool rowok = len > tn_ && act;
+            const __amdgpu_buffer_rsrc_t rs = lp_rsrc(DZ + (long long)tn_ * B * Ncat, (unsigned)B * (unsigned)Ncat * 2u);
+            const unsigned voff = rowok ? (unsigned)(b * Ncat + dir * Gp + (lane >> 4) * 8) * 2u : LP_OOB;
+            auto load_set = [&](int sg, u32x4 (&f)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] = lp_load16_sc1(rs, sg < nsg ? voff + (unsigned)(sg * 128 + q * 32) * 2u : LP_OOB);
+            };
+            auto mma_set = [&](int sg, const u32x4 (&f)[4]) {
+                if (sg >= nsg) return;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = sg * 16 + q * 4 + (lane >> 4);
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, f[q]);
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const int n = tn * 16 + (lane & 15);
+                        const bf16x8 bfr = *(const bf16x8*)(Wl + (long long)n * Gp + lp_wswz(n, ch, 15) * 8);
+                        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af, acc[tn], 0, 0, 0);
+                    }
+                }
+            };
+            u32x4 f0[4], f1[4], f2[4];
+            load_set(0, f0);
+            load_set(1, f1);
+            load_set(2, f2);
+#pragma nounroll
+            for (int sg = 0; sg < nsg; sg += 3) {
+                mma_set(sg, f0);
+                load_set(sg + 3, f0);
+                mma_set(sg + 1, f1);
+                load_set(sg + 4, f1);
+                mma_set(sg + 2, f2);
+                load_set(sg + 5, f2);
+            }
+        }
+        // ---- gate derivatives; publish dZ_t ----------------------------------------------------------
+        if (act) {
+            bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const f32x4 dh = acc[tn] + edhf[tn];
+                const f32x4 dcin = (tn_ >= 0 && tn_ < T && len > tn_) ? dcreg[tn] : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 zi, zf, zg, zo, dcn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tc = tanhf_(ec[tn][e]);
+                    const float d_o = dh[e] * tc;
+                    const float dct = dcin[e] + dh[e] * ego[tn][e] * (1.f - tc * tc);
+                    zi[e] = dct * egg[tn][e] * egi[tn][e] * (1.f - egi[tn][e]);
+                    zf[e] = dct * ecp[tn][e] * egf[tn][e] * (1.f - egf[tn][e]);
+                    zg[e] = dct * egi[tn][e] * (1.f - egg[tn][e] * egg[tn][e]);
+                    zo[e] = d_o * ego[tn][e] * (1.f - ego[tn][e]);
+                    dcn[e] = dct * egf[tn][e];
+                }
+                dcreg[tn] = dcn;
+                const f32x4 zz[4] = {zi, zf, zg, zo};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x2 pk = pack_bf16x4(zz[g]);
+                    __hip_atomic_store((gu64*)&zout[pcu[tn] + g * 16], (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 32),
+                                       SAD_RLX_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
+        ++done;
     }
 }
 

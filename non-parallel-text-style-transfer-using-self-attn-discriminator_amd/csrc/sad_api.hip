@@ -239,23 +239,27 @@ void launch_wg(K kernel, dim3 grid, hipStream_t st, Args... args) {
     hipLaunchKernelGGL(kernel, grid, dim3(W::NT), W::LDS_BYTES, st, args...);
 }
 
-// The persistent recurrence needs every workgroup co-resident (they wait for each other): the grid
+// The persistent recurrences need every workgroup co-resident (they wait for each other): the grid
 // must fit the device at the kernel's own occupancy.  SAD_NO_PERSIST=1 forces the per-step kernels.
-bool lstm_persist_fits(const Shape& s, int* grid) {
+bool persist_fits(const void* kernel, size_t lds, int grid) {
     const char* env = getenv("SAD_NO_PERSIST");      // read per call: tests switch paths in-process
-    const bool off = env != nullptr && atoi(env) != 0;
-    if (off || s.Hp > 64 * LP_KT_MAX || s.Gp % LP_BN != 0) return false;
-    const size_t lds = lstm_persist_lds_bytes(s.Hp);
+    if (env != nullptr && atoi(env) != 0) return false;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)k_lstm_fwd_persist,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_lstm_fwd_persist, 512, lds) != hipSuccess)
-        return false;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds) != hipSuccess) return false;
+    return per_cu >= 1 && grid <= per_cu * cus;
+}
+bool lstm_persist_fits(const Shape& s, int* grid) {
+    if (s.Hp > 64 * LP_KT_MAX || s.Gp % LP_BN != 0 || (long long)s.B * s.Hp * 4 >= (1ll << 31)) return false;
     *grid = 2 * ceil_div(s.B, LP_BM) * (s.Gp / LP_BN);
-    return per_cu >= 1 && *grid <= per_cu * cus;
+    return persist_fits((const void*)k_lstm_fwd_persist, lstm_persist_lds_bytes(s.Hp), *grid);
+}
+bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
+    if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
+    *grid = 2 * ceil_div(s.B, LB_BM) * (s.Hp / LB_BN);
+    return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid);
 }
 
 template <typename OutT>
@@ -555,12 +559,21 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
                            at<bf16raw>(packed, pl.whb0T), (const float*)nullptr, DHFIN, 2 * s.Hp);
         SAD_CHECK_LAUNCH("k_linear(bwd)");
     }
-    // K2': BPTT
-    for (int step = 0; step < s.T; ++step) {
-        typedef CfgStepBwd C;
-        dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
-        hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whhT), G, Cs,
-                           DHFIN, DC, DZ);
+    // K2': BPTT.  Persistent kernel (one launch) when its grid is co-resident, else T launches.
+    int pgrid = 0;
+    if (lstm_bwd_persist_fits(s, &pgrid)) {
+        unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
+        // counters only: the timeout words behind them keep what the forward left
+        (void)hipMemsetAsync(sync, 0, (size_t)2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH * 4, st);
+        hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), st, s, lens,
+                           at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, sync);
+    } else {
+        for (int step = 0; step < s.T; ++step) {
+            typedef CfgStepBwd C;
+            dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
+            hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whhT), G, Cs,
+                               DHFIN, DC, DZ);
+        }
     }
     SAD_CHECK_LAUNCH("k_lstm_bwd");
     // K2a' + K3'

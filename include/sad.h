@@ -79,6 +79,10 @@ typedef struct sad_fwd_args {
     float* logits;            /* out [B,L] */
     float* weights;           /* out [B,T] attention weights */
     float* loss;              /* out [B] or NULL */
+    const uint8_t* drop_keep; /* [T,B,E] bytes (time-major), 1 = keep, or NULL: inverted dropout on the embedded
+                                 tokens, X *= keep * drop_scale (classifier copy in training mode, reference
+                                 classifier/models.py:217; the caller draws the mask) */
+    float drop_scale;         /* 1 / (1 - p) */
 } sad_fwd_args;
 
 typedef struct sad_bwd_args {
@@ -93,6 +97,8 @@ typedef struct sad_bwd_args {
     int32_t dsrc_kind;
     int64_t dsrc_stride_b;
     int64_t dsrc_stride_t;
+    const uint8_t* drop_keep; /* the forward's dropout mask (or NULL) and scale: applied to d(embedded tokens) */
+    float drop_scale;
 } sad_bwd_args;
 
 /* Gradient tensors of the live parameters, fp32, state_dict layout (same shapes as sad_weights).

@@ -193,6 +193,29 @@ __global__ void k_embed_gather(Shape s, const long long* __restrict__ ids, long 
     }
 }
 
+// Inverted dropout on the embedded tokens (classifier copy in training mode, classifier/models.py:217),
+// with the caller's keep mask [M][E]:  X[m][e] = keep ? X[m][e] * scale : 0.  The same kernel masks
+// d(embedded tokens) in the backward.  One 16-byte chunk per thread.
+__global__ void k_apply_keep(Shape s, bf16raw* __restrict__ X, const unsigned char* __restrict__ keep, float scale) {
+    const int cpr = s.Ep / 8;
+    const long long total = (long long)s.M * cpr;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(c / cpr), e0 = (int)(c - (long long)m * cpr) * 8;
+        bf16raw* p = X + (long long)m * s.Ep + e0;
+        const u32x4 v = *(const u32x4*)p;
+        bf16raw out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16raw x = (bf16raw)((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+            const int e = e0 + i;
+            const bool k = e < s.E && keep[(long long)m * s.E + e] != 0;
+            out[i] = k ? f32_to_bf16(bf16_to_f32(x) * scale) : (bf16raw)0;
+        }
+        *(u32x4*)p = u32x4{out[0] | ((unsigned)out[1] << 16), out[2] | ((unsigned)out[3] << 16),
+                           out[4] | ((unsigned)out[5] << 16), out[6] | ((unsigned)out[7] << 16)};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2a + K3  fused input projection:  [G | Kk][m] = X[m] . Wcat^T + bcat
 // (nn.LSTM input GEMMs of both directions, transfer/models.py:779-785,906, and linear_emb, :925)

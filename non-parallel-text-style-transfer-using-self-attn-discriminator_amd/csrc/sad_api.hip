@@ -434,6 +434,15 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
         if (rc) return rc;
     }
 
+    // dropout on the embedded tokens (classifier copy, training mode)
+    if (a->drop_keep != nullptr) {
+        const long long chunks = (long long)s.M * (s.Ep / 8);
+        int blocks = (int)((chunks + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_apply_keep, dim3(blocks), dim3(256), 0, st, s, X, a->drop_keep, a->drop_scale);
+        SAD_CHECK_LAUNCH("k_apply_keep");
+    }
+
     // K2a + K3
     {
         if (s.Ep == 320 && s.Ncat % 64 == 0) {          // A-stationary fast path (E = 300)
@@ -593,6 +602,13 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
         if (ksplit > 1) launch_cvt(accf, DX, (long long)s.M * s.Ep, st);
     }
     SAD_CHECK_LAUNCH("k_inproj_bwd");
+    if (a->drop_keep != nullptr) {      // d(embedded tokens) in front of the dropout
+        const long long chunks = (long long)s.M * (s.Ep / 8);
+        int blocks = (int)((chunks + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_apply_keep, dim3(blocks), dim3(256), 0, st, s, DX, a->drop_keep, a->drop_scale);
+        SAD_CHECK_LAUNCH("k_apply_keep");
+    }
     // K1'
     if (a->dsrc != nullptr) {
         int rc = run_softemb_bwd(s, pl, wl, packed, ws, a->dsrc, a->dsrc_kind, a->dsrc_stride_b, a->dsrc_stride_t, st);

@@ -183,11 +183,14 @@ def _grad_struct(views):
     return g
 
 
-_N_FIXED = 7   # forward() arguments in front of *params
+_N_FIXED = 8   # forward() arguments in front of *params
 
 
 class _Discriminator(torch.autograd.Function):
-    """forward(src, lengths, mask, labels, pw, guard, pad_id, *params).
+    """forward(src, lengths, mask, labels, pw, guard, pad_id, drop, *params).
+
+    ``drop`` is None or (keep [T,B,E] bool/uint8 CUDA tensor, scale): inverted dropout on the embedded
+    tokens with the caller's mask (classifier copy in training mode, reference classifier/models.py:217).
 
     ``params`` is either empty (frozen discriminator: the transfer loop, reference
     transfer/trainers.py:216-223) or the 19 live parameters in ``_LIVE_PARAMS`` order; those that
@@ -195,7 +198,7 @@ class _Discriminator(torch.autograd.Function):
     classifier/trainers.py:367-373)."""
 
     @staticmethod
-    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, *params):
+    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, drop, *params):
         if not src.is_cuda:
             raise RuntimeError("sad_amd runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
         if params and len(params) != len(_LIVE_PARAMS):
@@ -226,6 +229,14 @@ class _Discriminator(torch.autograd.Function):
         a.labels = labels.data_ptr() if labels is not None else None
         a.logits, a.weights = logits.data_ptr(), weights.data_ptr()
         a.loss = loss.data_ptr() if loss is not None else None
+        if drop is not None:
+            keep, scale = drop
+            keep = keep.to(device=dev).contiguous().view(torch.uint8) if keep.dtype == torch.bool else keep.to(
+                device=dev, dtype=torch.uint8).contiguous()
+            if tuple(keep.shape) != (T, B, pw.E):
+                raise RuntimeError("dropout keep mask must be [T,B,E] = %s, got %s" % ((T, B, pw.E), tuple(keep.shape)))
+            a.drop_keep, a.drop_scale = keep.data_ptr(), float(scale)
+            drop = (keep, float(scale))
         with torch.cuda.device(dev):
             _lib.check(_lib.load().sad_forward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
                                                _stream_ptr()), "sad_forward")
@@ -236,7 +247,7 @@ class _Discriminator(torch.autograd.Function):
         # the forward input is needed again for d embedding.weight (S^T . dX / scatter-add by id)
         keep_src = src if (params and ctx.needs_input_grad[_N_FIXED]) else None
         ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype, labels, logits, weights, keep_src,
-                   -1 if pad_id is None else int(pad_id), [tuple(p.shape) for p in params])
+                   -1 if pad_id is None else int(pad_id), [tuple(p.shape) for p in params], drop)
         _Discriminator.last_workspace = ws   # introspection hook for tests / profiling
         if loss is None:
             return logits, weights
@@ -244,7 +255,7 @@ class _Discriminator(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits, dweights, dloss=None):
-        d, ws, pw, kind, shape, strides, dtype, labels, logits, weights, src, pad_id, pshapes = ctx.sad
+        d, ws, pw, kind, shape, strides, dtype, labels, logits, weights, src, pad_id, pshapes, drop = ctx.sad
         n_out = _N_FIXED + len(pshapes)
         want_src = kind != _lib.SRC_IDS and ctx.needs_input_grad[0]
         want_p = [bool(x) for x in ctx.needs_input_grad[_N_FIXED:]]
@@ -284,6 +295,8 @@ class _Discriminator(torch.autograd.Function):
         if dsrc is not None:
             a.dsrc, a.dsrc_kind = dsrc.data_ptr(), kind
             a.dsrc_stride_b, a.dsrc_stride_t = dsrc.stride(0), dsrc.stride(1)
+        if drop is not None:
+            a.drop_keep, a.drop_scale = drop[0].data_ptr(), drop[1]
         pgrads = [None] * len(pshapes)
         with torch.cuda.device(dev):
             lib = _lib.load()
@@ -307,7 +320,7 @@ class _Discriminator(torch.autograd.Function):
                                                           _ptr(ws.buf), _stream_ptr()), "sad_param_grads_accumulate")
                 _Discriminator.last_grad_bucket = flat
         del keep
-        return (dsrc, None, None, None, None, None, None) + tuple(pgrads)
+        return (dsrc, None, None, None, None, None, None, None) + tuple(pgrads)
 
 
 def _live(params):
@@ -317,18 +330,18 @@ def _live(params):
     return tuple(params[n] for n in _LIVE_PARAMS)
 
 
-def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None):
+def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None, drop=None):
     """(logits [B,L], attention weights [B,T]) — the reference module's return value.
 
     ``params`` (name -> nn.Parameter, optional) makes the call differentiable w.r.t. the parameters
     that require grad; without it the discriminator is frozen (gradient flows to soft tokens only)."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, *_live(params))
+    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, drop, *_live(params))
 
 
-def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None):
+def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None, drop=None):
     """(per-sentence CE loss [B], logits, weights) with the cross entropy fused into the attention
     kernels — what the transfer step computes at reference transfer/models.py:1185-1212."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, *_live(params))
+    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, drop, *_live(params))
     return loss, logits, weights

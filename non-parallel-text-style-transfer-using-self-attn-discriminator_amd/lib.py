@@ -58,6 +58,7 @@ class SadFwdArgs(ctypes.Structure):
         ("mask", c_void_p), ("mask_stride_b", c_int64), ("mask_stride_t", c_int64), ("guard", c_int32),
         ("labels", c_void_p),
         ("logits", c_void_p), ("weights", c_void_p), ("loss", c_void_p),
+        ("drop_keep", c_void_p), ("drop_scale", c_float),
     ]
 
 
@@ -66,6 +67,7 @@ class SadBwdArgs(ctypes.Structure):
         ("dlogits", c_void_p), ("labels", c_void_p), ("dloss", c_void_p), ("dloss_scale", c_float),
         ("dweights", c_void_p), ("logits", c_void_p), ("weights", c_void_p),
         ("dsrc", c_void_p), ("dsrc_kind", c_int32), ("dsrc_stride_b", c_int64), ("dsrc_stride_t", c_int64),
+        ("drop_keep", c_void_p), ("drop_scale", c_float),
     ]
 
 

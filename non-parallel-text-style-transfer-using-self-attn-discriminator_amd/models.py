@@ -93,7 +93,7 @@ class _SelfAttnBase(nn.Module):
             return live
         return None
 
-    def _run(self, src, src_len, mask, hidden, soft, guard):
+    def _run(self, src, src_len, mask, hidden, soft, guard, drop=None):
         if hidden is not None:
             raise NotImplementedError("an initial hidden state is never passed by the reference callers")
         if soft and src.dim() != 3:
@@ -101,7 +101,7 @@ class _SelfAttnBase(nn.Module):
         if not soft and src.dim() != 2:
             raise RuntimeError("soft=False expects [B,T] token ids")
         return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard, params=self._trainable(),
-                                pad_id=self.embedding.padding_idx)
+                                pad_id=self.embedding.padding_idx, drop=drop)
 
     def loss(self, src, src_len, mask, labels, soft=True):
         """Fused variant: per-sentence CE vs ``labels`` computed inside the attention kernels
@@ -133,15 +133,18 @@ class ClassifierSelfAttnRNNClassifier(_SelfAttnBase):
         return torch.cat([ones, pad_mask[:, 2:], ones], dim=1)
 
     def forward(self, src, src_len, pad_mask=None, hidden=None, soft=False):
+        drop = None
         if self.training and self.dropout_p > 0.0:
-            # SURVEY.md §8 f1 ("next" row): dropout on the embedded tokens (classifier/models.py:217)
-            raise NotImplementedError("dropout on embedded tokens (training mode, p>0) is not implemented yet; "
-                                      "use eval() or dropout=0")
+            # dropout on the embedded tokens [T,B,E] (classifier/models.py:217): the mask is drawn here with
+            # torch's generator (plumbing), the kernels apply it in the forward and in the backward
+            B, T = src.shape[0], src.shape[1]
+            keep = torch.rand((T, B, self.embedding.embedding_dim), device=src.device) >= self.dropout_p
+            drop = (keep, 1.0 / (1.0 - self.dropout_p))
         if pad_mask is None:
             mask = torch.zeros(src.shape[:2], dtype=torch.bool, device=src.device)
         else:
             mask = self._pad_sos_eos_mask(pad_mask)
-        return self._run(src, src_len, mask, hidden, soft, guard=False)
+        return self._run(src, src_len, mask, hidden, soft, guard=False, drop=drop)
 
     def get_masked_src(self, src, src_len, pad_mask):
         """classifier/models.py:269-299 (thin post-processing around forward)."""

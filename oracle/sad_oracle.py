@@ -106,13 +106,15 @@ def lstm_dir_backward(dh_final, cache, lengths, W_ih, W_hh, reverse):
     return dZ
 
 
-def forward(params, src, lengths, mask, soft, labels=None, mutate_mask=True, guard=True):
+def forward(params, src, lengths, mask, soft, labels=None, mutate_mask=True, guard=True, drop=None):
     """Full discriminator forward (transfer/models.py:885-953; attention :841-883;
     per-sentence CE = nn.CrossEntropyLoss(reduction='none'), transfer/models.py:990,1212).
 
     src: [B,T,V] float (soft) or [B,T] int;  lengths [B] (sorted desc, >= 2);  mask [B,T] bool,
     True = pad/sos/eos.  ``guard`` applies the all-masked-row fix of the transfer copy (the
     classifier copy, classifier/models.py:161-197, has none).
+    ``drop`` = (keep [B,T,E] bool, scale) applies inverted dropout to the embedded tokens
+    (classifier copy in training mode, classifier/models.py:217).
     Returns dict(logits [B,L], weights [B,T], loss [B] or None, cache)."""
     lengths = np.asarray(lengths).astype(np.int64)
     if not mutate_mask:
@@ -120,6 +122,8 @@ def forward(params, src, lengths, mask, soft, labels=None, mutate_mask=True, gua
     if guard:
         guard_mask_inplace(mask)
     X = embed(params, src, soft)
+    if drop is not None:
+        X = X * (np.asarray(drop[0]) * drop[1]).astype(X.dtype)
     dt = X.dtype
     h_f, cf = lstm_dir_forward(X, lengths, params["rnn.weight_ih_l0"], params["rnn.weight_hh_l0"],
                                params["rnn.bias_ih_l0"], params["rnn.bias_hh_l0"], False)
@@ -145,7 +149,7 @@ def forward(params, src, lengths, mask, soft, labels=None, mutate_mask=True, gua
         lse = np.log(np.exp(z).sum(axis=1))
         loss = lse - z[np.arange(len(labels)), labels]
     cache = dict(X=X, cf=cf, cb=cb, hcat=hcat, q=q, u=u, Kk=Kk, mid=mid, a=a, ctx=ctx,
-                 mask=mask, lengths=lengths, soft=soft, src=src)
+                 mask=mask, lengths=lengths, soft=soft, src=src, drop=drop)
     return dict(logits=logits, weights=a, loss=loss, cache=cache)
 
 
@@ -189,7 +193,10 @@ def backward(params, cache, dlogits, dweights=None, want_param_grads=False):
     dX = dKk @ params["linear_emb.weight"]
     dX = dX + np.einsum("tbg,ge->bte", dZf, params["rnn.weight_ih_l0"])
     dX = dX + np.einsum("tbg,ge->bte", dZb, params["rnn.weight_ih_l0_reverse"])
-    out = dict(dX=dX, dKk=dKk, dZf=dZf, dZb=dZb, du=du, dq=dq, dhcat=dhcat, dctx=dctx)
+    dXd = dX                                    # gradient w.r.t. the (dropped) LSTM / key input
+    if cache.get("drop") is not None:           # ... and w.r.t. the embedding output in front of the dropout
+        dX = dX * (np.asarray(cache["drop"][0]) * cache["drop"][1]).astype(dt)
+    out = dict(dX=dX, dXd=dXd, dKk=dKk, dZf=dZf, dZb=dZb, du=du, dq=dq, dhcat=dhcat, dctx=dctx)
     if cache["soft"]:
         out["dS"] = dX @ params["embedding.weight"].T
     if want_param_grads:

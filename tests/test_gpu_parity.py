@@ -112,6 +112,44 @@ def test_param_grads_yelp_hard_b64():
     assert max(errs.values()) < BF16_TOL_WGRAD, errs
 
 
+def test_classifier_dropout_training_golden():
+    """Classifier copy, training mode, dropout p=0.3 on the embedded tokens (classifier/models.py:217),
+    with the keep mask the REFERENCE drew: outputs and all 19 parameter gradients vs its autograd."""
+    hdr, d, params, want = load_golden("tiny_hard_dropout_f64.npz")
+    mask = synth.classifier_mask(d["ids"] == 0)
+    drop = (d["keep"], 1.0 / (1.0 - hdr["p_drop"]))
+    out = run_sad(params, d["ids"], d["lengths"], mask, d["labels"], soft=False, guard=False, param_grads=True,
+                  pad_id=0, drop=drop)
+    errs = _grad_errors(out["grads"], want)
+    errs["logits"] = relerr(out["logits"], d["logits"])
+    errs["weights"] = relerr(out["weights"], d["weights"])
+    _report("classifier dropout training golden", errs)
+    assert max(errs.values()) < BF16_TOL_WGRAD, errs
+    # the module draws its own mask in train() mode and none in eval() mode
+    import torch
+    from types import SimpleNamespace
+    from sad_amd import classifier_models
+    cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=hdr["p_drop"], enc_num_layers=1,
+                          hidden_size=hdr["H"], vocab_size=hdr["V"], emb_size=hdr["E"], num_labels=2,
+                          freeze_embedding=False, device="cuda:0", mask_id=None)
+    mc = classifier_models.SelfAttnRNNClassifier(cfg)
+    mc.load_state_dict({k: torch.from_numpy(v.astype(np.float32)) for k, v in params.items()})
+    mc.to("cuda:0")
+    ids = torch.from_numpy(d["ids"]).cuda()
+    ln = torch.from_numpy(d["lengths"])
+    mc.eval()
+    with torch.no_grad():
+        e1, _ = mc(ids, ln, ids == 0)
+        e2, _ = mc(ids, ln, ids == 0)
+    assert torch.equal(e1, e2)
+    mc.train()
+    t1, _ = mc(ids, ln, ids == 0)
+    t2, _ = mc(ids, ln, ids == 0)
+    assert not torch.equal(t1, t2) and torch.isfinite(t1).all()
+    torch.nn.functional.cross_entropy(t1, torch.from_numpy(d["labels"]).cuda()).backward()
+    assert mc.embedding.weight.grad is not None and torch.isfinite(mc.embedding.weight.grad).all()
+
+
 def test_param_grads_ragged_vs_oracle_and_frozen_subset():
     """Odd sizes (H, E not multiples of the tile sizes, ragged lengths, several row splits) vs the
     oracle; then the same call with the embedding frozen (freeze_emb) and one bias frozen: frozen

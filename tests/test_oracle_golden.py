@@ -113,3 +113,21 @@ def test_torch_ref_matches_golden():
     loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(d["labels"]), reduction="none")
     (loss.sum() / B).backward()
     assert relerr(S.grad.numpy(), d["dS"]) < 1e-11
+
+
+def test_classifier_dropout_training_step():
+    """Classifier copy in training mode with dropout on the embedded tokens (classifier/models.py:217):
+    the fixture holds the keep mask the reference drew, its outputs and parameter gradients."""
+    hdr, d, params, grads = load_golden("tiny_hard_dropout_f64.npz")
+    ids, lengths = d["ids"], d["lengths"]
+    mask = synth.classifier_mask(ids == 0)
+    drop = (d["keep"].transpose(1, 0, 2), 1.0 / (1.0 - hdr["p_drop"]))
+    f = O.forward(params, ids, lengths, mask, False, labels=d["labels"], guard=False, drop=drop)
+    assert relerr(f["logits"], d["logits"]) < 1e-12
+    assert relerr(f["weights"], d["weights"]) < 1e-12
+    B = len(d["labels"])
+    dlog = O.ce_dlogits(f["logits"], d["labels"], np.full((B,), 1.0 / B))
+    b = O.backward(params, f["cache"], dlog, want_param_grads=True)
+    assert len(grads) == 19
+    for k, g in grads.items():
+        assert relerr(b["grads"][k], g, floor=1e-3) < 1e-10, k

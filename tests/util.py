@@ -45,10 +45,11 @@ def bf16_round(x):
 
 def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", time_major=True,
             dloss=None, fused_loss=True, guard=True, want_ws=False, dweights=None, param_grads=False,
-            frozen=(), pad_id=None):
+            frozen=(), pad_id=None, drop=None):
     """Run libsad forward (+ backward when soft) on cuda:0 through the Python binding.
 
     src: numpy [B,T,V] float / [B,T] int64 (batch-major, like the oracle takes it).
+    drop: (keep [T,B,E] bool numpy, scale) dropout on the embedded tokens.
     param_grads: also back-propagate into the parameters (all but the names in `frozen`);
     out["grads"] = {name: numpy}.
     Returns dict of numpy arrays (logits, weights, loss, mask_after, dS [B,T,V], ws fields)."""
@@ -77,11 +78,13 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
     m = torch.from_numpy(mask.copy()).to(dev)
     ln = torch.from_numpy(np.asarray(lengths).astype(np.int32))
     out = {}
+    if drop is not None:
+        drop = (torch.from_numpy(np.ascontiguousarray(drop[0])).to(dev), float(drop[1]))
     if labels is not None and fused_loss:
         lab = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(dev)
-        loss, logits, weights = Fn.discriminator_loss(x, ln, m, lab, pw, guard=guard, params=live, pad_id=pad_id)
+        loss, logits, weights = Fn.discriminator_loss(x, ln, m, lab, pw, guard=guard, params=live, pad_id=pad_id, drop=drop)
     else:
-        logits, weights = Fn.discriminator(x, ln, m, pw, guard=guard, params=live, pad_id=pad_id)
+        logits, weights = Fn.discriminator(x, ln, m, pw, guard=guard, params=live, pad_id=pad_id, drop=drop)
         loss = None
         if labels is not None:
             lab = torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(dev)

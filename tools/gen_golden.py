@@ -31,16 +31,16 @@ import torch.nn.functional as F  # noqa: E402
 from sad_amd import synth  # noqa: E402
 
 
-def ref_config(V, E, H, L=2):
-    return SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0,
+def ref_config(V, E, H, L=2, dropout=0.0):
+    return SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=dropout,
                            enc_num_layers=1, hidden_size=H, vocab_size=V, emb_size=E,
                            num_labels=L, freeze_embedding=False, device="cpu", mask_id=None)
 
 
-def build_ref(which, V, E, H, params, dtype):
+def build_ref(which, V, E, H, params, dtype, dropout=0.0):
     import importlib
     mod = importlib.import_module("%s.models" % which)   # /root/reference/{transfer,classifier}/models.py
-    m = mod.SelfAttnRNNClassifier(ref_config(V, E, H))
+    m = mod.SelfAttnRNNClassifier(ref_config(V, E, H, dropout=dropout))
     sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
     assert list(m.state_dict().keys()) == list(params.keys()), "state_dict layout drifted"
     m = m.to(dtype)          # cast first: load_state_dict copies INTO the existing dtype
@@ -143,6 +143,42 @@ def tiny_cases(outdir):
     save(os.path.join(outdir, "tiny_hard_f64.npz"), hdr, **arrs)
 
 
+def dropout_case(outdir):
+    """Classifier copy in TRAINING mode with dropout p=0.3 on the embedded tokens
+    (classifier/models.py:217).  nn.Dropout draws `empty_like(x).bernoulli_(1-p)` from the global
+    generator as its first random draw, so the same seed reproduces the keep mask, which is stored
+    with the outputs and the parameter gradients of the mean CE loss."""
+    V, E, H, B, T, p_drop = 41, 10, 8, 5, 9, 0.3
+    lengths = np.array([9, 7, 5, 4, 3], dtype=np.int32)
+    params = synth.make_params(V, E, H, seed=11, dtype=np.float64)
+    labels = synth.make_labels(B, seed=3)
+    ids = synth.make_token_ids(B, T, V, lengths, seed=9)
+    m = build_ref("classifier", V, E, H, params, torch.float64, dropout=p_drop)
+    m.train()
+    pad_mask = torch.from_numpy(ids == 0)
+    torch.manual_seed(4321)
+    logits, weights = m(torch.from_numpy(ids), torch.from_numpy(lengths), pad_mask)
+    loss = F.cross_entropy(logits, torch.from_numpy(labels), reduction="none")
+    for q in m.parameters():
+        q.grad = None
+    (loss.sum() / B).backward()
+    torch.manual_seed(4321)
+    keep = torch.empty((T, B, E), dtype=torch.float64).bernoulli_(1 - p_drop).numpy() != 0     # [T,B,E]
+    arrs = dict(ids=ids, lengths=lengths, labels=labels, keep=keep, logits=logits.detach().numpy(),
+                weights=weights.detach().numpy(), loss=loss.detach().numpy())
+    none_grads = []
+    for k, q in m.named_parameters():
+        if q.grad is None:
+            none_grads.append(k)
+        else:
+            arrs["grad:" + k] = q.grad.numpy()
+    for k, v in params.items():
+        arrs["param:" + k] = v
+    hdr = dict(case="tiny_hard_dropout_f64", V=V, E=E, H=H, B=B, T=T, L=2, param_seed=11, id_seed=9, label_seed=3,
+               p_drop=p_drop, torch_seed=4321, none_grads=none_grads, **versions())
+    save(os.path.join(outdir, "tiny_hard_dropout_f64.npz"), hdr, **arrs)
+
+
 def yelp_soft_cases(outdir):
     """Transfer-shaped soft call: B=8, T=23, Yelp dims, int16 lengths."""
     V, E, H, B, T = 9353, 300, 512, 8, 23
@@ -224,11 +260,16 @@ def yelp_hard_case(outdir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None, help="regenerate one family: dropout")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if a.only == "dropout":
+        dropout_case(a.out)
+        return
     tiny_cases(a.out)
+    dropout_case(a.out)
     yelp_soft_cases(a.out)
     yelp_hard_case(a.out)
 

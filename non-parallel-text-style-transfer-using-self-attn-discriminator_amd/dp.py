@@ -38,6 +38,23 @@ def global_mean_loss(local_loss_sum, local_count):
     return v[0] / v[1]
 
 
+def _as_one_bucket(grads, n):
+    """If the gradients are contiguous fp32 views laid out back to back in one storage (what the
+    discriminator's backward produces: one zero-filled bucket, one view per live tensor), return that
+    span as a flat tensor sharing their memory, else None."""
+    g0 = grads[0]
+    if g0.dtype != torch.float32:
+        return None
+    base = g0.untyped_storage().data_ptr()
+    off = g0.storage_offset()
+    for g in grads:
+        if (g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base
+                or g.storage_offset() != off):
+            return None
+        off += g.numel()
+    return torch.as_strided(g0, (n,), (1,), g0.storage_offset())
+
+
 def allreduce_grads(params, bucket=None):
     """Sum-all-reduce the gradients of `params` (those with a grad) as ONE flat fp32 bucket:
     xGMI is point-to-point, so one large collective beats many small ones.  With the local loss
@@ -47,13 +64,19 @@ def allreduce_grads(params, bucket=None):
     if not grads:
         return bucket
     n = sum(g.numel() for g in grads)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    flat = _as_one_bucket(grads, n)
+    if flat is not None:            # the backward already wrote the gradients back to back: no copies
+        if multi:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
     if bucket is None or bucket.numel() != n or bucket.device != grads[0].device:
         bucket = torch.empty(n, dtype=torch.float32, device=grads[0].device)
     o = 0
     for g in grads:
         bucket[o:o + g.numel()].copy_(g.reshape(-1))
         o += g.numel()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if multi:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
     o = 0
     for g in grads:

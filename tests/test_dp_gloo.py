@@ -53,6 +53,14 @@ def _worker(rank, world, port, q):
         loss_b = ((x[lo:hi] @ w) * v).sum(dim=1) ** 2          # per-sentence loss
         (loss_b.sum() / B).backward()                          # local loss scaled by 1/global_B
         dp.allreduce_grads([w, v, dead])
+        # second form: gradients that already sit back to back in one bucket (what the discriminator's
+        # backward returns) are reduced in place, without the gather/scatter copies
+        flat = torch.cat([w.grad.reshape(-1), v.grad.reshape(-1)]).clone() / world   # undo the sum: per-rank share
+        w2, v2 = torch.nn.Parameter(w.detach().clone()), torch.nn.Parameter(v.detach().clone())
+        w2.grad, v2.grad = flat[:w.numel()].view_as(w), flat[w.numel():].view_as(v)
+        out = dp.allreduce_grads([w2, v2])
+        assert out.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        assert torch.allclose(w2.grad, w.grad) and torch.allclose(v2.grad, v.grad)
         mean = dp.global_mean_loss(loss_b.sum(), hi - lo)
         q.put((rank, w.grad.numpy().copy(), v.grad.numpy().copy(), dead.grad is None, float(mean)))
     finally:

@@ -1018,6 +1018,180 @@ __global__ __launch_bounds__(512) void k_softemb_bwd_rs(Shape s, const bf16raw* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised form of rs_gemm (K1'): 8 COMPUTE waves (A fragments in registers, MFMAs,
+// epilogue stores) + 4 LOADER waves (Bt tiles -> LDS) in one 768-thread workgroup.
+// vmcnt retires in order per wave, so a wave that both prefetches tiles and stores results has to
+// drain its stores whenever it waits for a tile; here the compute waves issue nothing but stores
+// after their one-time fragment loads and never wait on vector memory, and the loaders keep two
+// tiles of loads in flight (two register sets) while one tile is being written to the spare LDS
+// buffer.  Two LDS tile buffers, one workgroup barrier per tile.
+// PAIR / epi: as in rs_gemm.  Bs: 2 * 64 * KS * 64 bytes.
+// ------------------------------------------------------------------------------------------------
+template <int KS, bool PAIR, class Epi>
+__device__ __forceinline__ void rs_gemm_ws(const bf16raw* __restrict__ A, int M, const int (&mrow)[2], bool wave_any,
+                                           const bf16raw* __restrict__ Bt, int nt0, int nt1, unsigned char* Bs, Epi epi) {
+    constexpr int EP = KS * 32, BN = 64, NLOAD = 256;
+    constexpr int ROWB = EP * 2;              // bytes per Bt row
+    constexpr int CPR = EP / 8;               // 16-byte chunks per row
+    constexpr int SCH = BN * CPR / NLOAD;     // staging chunks per loader thread and tile
+    constexpr int TILEB = BN * ROWB;
+    static_assert((BN * CPR) % NLOAD == 0, "tile must split evenly over the loader waves");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave >= 8) {
+        // ---------------------------------- loader waves ---------------------------------------
+        const int lt = tid - 512;
+        int soff[SCH], goff[SCH];
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) {
+            const int g = lt + i * NLOAD;
+            const int vloc = g / CPR, ch = g - vloc * CPR;
+            const int rho = PAIR ? (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3) : vloc;
+            soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
+            goff[i] = g * 8;
+        }
+        u32x4 st[2][SCH];
+        auto load_tile = [&](auto par, int nt) {      // clamped, never skipped: static operation counts
+            constexpr int P = decltype(par)::value;
+            const bf16raw* base = Bt + (long long)(nt < nt1 ? nt : nt1 - 1) * BN * EP;
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) st[P][i] = *(const u32x4*)(base + goff[i]);
+        };
+        auto to_lds = [&](auto par, int nt) {         // tile nt (register set nt&1) -> LDS buffer nt&1
+            constexpr int P = decltype(par)::value;
+            unsigned char* buf = Bs + ((nt - nt0) & 1) * TILEB;
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) *(u32x4*)&buf[soff[i]] = st[P][i];
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        load_tile(P0{}, nt0);
+        load_tile(P1{}, nt0 + 1);
+        to_lds(P0{}, nt0);
+        load_tile(P0{}, nt0 + 2);
+        __syncthreads();                              // tile nt0 ready
+        for (int nt = nt0; nt < nt1; nt += 2) {
+            // during compute(nt): tile nt+1 -> other buffer, request nt+3
+            to_lds(P1{}, nt + 1);
+            load_tile(P1{}, nt + 3);
+            __syncthreads();
+            if (nt + 1 < nt1) {
+                to_lds(P0{}, nt + 2);
+                load_tile(P0{}, nt + 4);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    // -------------------------------------- compute waves ----------------------------------------
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(A + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
+            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    int roff[4], rsw[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int rho = tn * 16 + (lane & 15);
+        roff[tn] = rho * ROWB;
+        rsw[tn] = (rho >> 1) & 7;
+    }
+    __syncthreads();                                  // tile nt0 ready
+    for (int nt = nt0; nt < nt1; ++nt) {
+        const unsigned char* buf = Bs + ((nt - nt0) & 1) * TILEB;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave_any) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 bfr[4];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    bfr[tn] = *(const bf16x8*)&buf[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+                    epi(tm, nt * BN + 32 * pr + 8 * (lane >> 4), acc[tm][2 * pr], acc[tm][2 * pr + 1]);
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) epi(tm, nt * BN + 16 * tn + 4 * (lane >> 4), acc[tm][tn]);
+            }
+        }
+        __syncthreads();                              // tile nt consumed; tile nt+1 written by the loaders
+    }
+}
+
+// K1' on rs_gemm_ws.  Same contract as k_softemb_bwd_rs.
+template <int KS, int KIND>
+__global__ __launch_bounds__(768) void k_softemb_bwd_ws(Shape s, const bf16raw* __restrict__ DX,
+                                                       const unsigned char* __restrict__ need,
+                                                       const bf16raw* __restrict__ wemb, void* __restrict__ dS,
+                                                       long long sT, long long sB, int nt_per) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];   // 2 * 64 * KS * 64 bytes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 256;
+    const int ntiles = s.Vp / 64;
+    const int nt0 = blockIdx.y * nt_per;
+    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
+    const int M = s.M, V = s.V;
+    int mrow[2];
+    long long obase[2];
+    int rneed = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = m0 + (wave & 7) * 32 + tm * 16 + (lane & 15);
+        mrow[tm] = m;
+        obase[tm] = 0;
+        if (m < M) {
+            const int t = m / s.B, b = m - t * s.B;
+            obase[tm] = (long long)t * sT + (long long)b * sB;
+            if (wave < 8) rneed |= need[m];
+        }
+    }
+    const bool wave_any = __any(rneed != 0);
+    if constexpr (KIND == SRC_F32) {
+        rs_gemm_ws<KS, false>(DX, M, mrow, wave_any, wemb, nt0, nt1, ws_lds, [&](int tm, int n, f32x4 v) {
+            if (mrow[tm] >= M || n >= V) return;
+            float* p = (float*)dS + obase[tm] + n;
+            if (n + 4 <= V) {
+                *(f32x4u*)p = v;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < V) p[e] = v[e];
+            }
+        });
+    } else {
+        rs_gemm_ws<KS, true>(DX, M, mrow, wave_any, wemb, nt0, nt1, ws_lds, [&](int tm, int n, f32x4 lo, f32x4 hi) {
+            if (mrow[tm] >= M || n >= V) return;
+            bf16raw* p = (bf16raw*)dS + obase[tm] + n;
+            if (n + 8 <= V) {
+                *(u32x4h*)p = pack_bf16x8(lo, hi);
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < V) p[e] = f32_to_bf16(lo[e]);
+                    if (n + 4 + e < V) p[4 + e] = f32_to_bf16(hi[e]);
+                }
+            }
+        });
+    }
+}
+
 // K2a + K3 fast path (Ep == 32*KS, Ncat % 64 == 0): [G | Kk][m] = X[m] . Wcat^T + bcat.
 // Rows nobody reads (need == 0) are not written.
 template <int KS>

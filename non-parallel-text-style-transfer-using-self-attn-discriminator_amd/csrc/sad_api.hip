@@ -206,6 +206,27 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     vsplit = vsplit < 1 ? 1 : (vsplit > ntiles ? ntiles : vsplit);
     const int nt_per = ceil_div(ntiles, vsplit);
     const dim3 rs_grid(mtiles, ceil_div(ntiles, nt_per));
+    static const bool use_ws = getenv("SAD_K1B_WS") == nullptr || atoi(getenv("SAD_K1B_WS")) != 0;   // A/B switch
+    if (rs && use_ws) {
+        constexpr size_t lds = 2 * 64 * 10 * 64;
+        if (kind == SAD_SRC_F32) {
+            if (check_aligned(dsrc, 4, "dsrc")) return -1;
+            static const hipError_t e1 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws<10, SRC_F32>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)e1;
+            hipLaunchKernelGGL((k_softemb_bwd_ws<10, SRC_F32>), rs_grid, dim3(768), lds, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
+        } else if (kind == SAD_SRC_BF16) {
+            if (check_aligned(dsrc, 2, "dsrc")) return -1;
+            static const hipError_t e2 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws<10, SRC_BF16>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)e2;
+            hipLaunchKernelGGL((k_softemb_bwd_ws<10, SRC_BF16>), rs_grid, dim3(768), lds, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
+        } else {
+            return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
+        }
+        SAD_CHECK_LAUNCH("k_softemb_bwd_ws");
+        return 0;
+    }
     if (kind == SAD_SRC_F32) {
         if (check_aligned(dsrc, 4, "dsrc")) return -1;
         if (rs) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_F32>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);

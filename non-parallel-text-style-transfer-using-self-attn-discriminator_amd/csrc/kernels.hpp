@@ -1192,6 +1192,175 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws(Shape s, const bf16raw* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1' for bf16 dS with LOADER, COMPUTE and STORE waves (768 threads):
+//   waves 0-7  compute: dX fragments in registers, 80 MFMAs per 64-column tile, results -> LDS
+//   waves 8-9  loaders: W_emb tile nt+1 -> LDS while tile nt is multiplied
+//   waves 10-11 storers: tile nt-1 from LDS -> dS, 128 contiguous bytes per row and 8 rows per
+//              instruction (the accumulator layout only gives 64-byte pieces of 16 rows)
+// A wave that multiplies and also stores alternates between the two (store issue stalls when the
+// memory pipe is full, and all waves meet at the tile barrier), so the kernel ran at store time +
+// MFMA time; with the roles split the tile time is the maximum of the three.
+// LDS: 2 W_emb tile buffers (2 x 40 KB at E = 300) + 2 output tile buffers (2 x 32 KB), one
+// workgroup barrier per tile.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw* __restrict__ DX,
+                                                        const unsigned char* __restrict__ need,
+                                                        const bf16raw* __restrict__ wemb, bf16raw* __restrict__ dS,
+                                                        long long sT, long long sB, int nt_per) {
+    constexpr int EP = KS * 32, BN = 64;
+    constexpr int ROWB = EP * 2, CPR = EP / 8, TILEB = BN * ROWB;
+    constexpr int NLOAD = 128, SCH = BN * CPR / NLOAD;        // loader threads, chunks per thread and tile
+    constexpr int OUTB = 256 * BN * 2;                        // one output tile: [256][64] bf16
+    static_assert((BN * CPR) % NLOAD == 0, "tile must split evenly over the loader waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char w2_lds[];
+    unsigned char* Bs = w2_lds;                                // 2 x TILEB
+    unsigned char* Os = w2_lds + 2 * TILEB;                    // 2 x OUTB, chunk c of row r at r*128 + ((c ^ (r&7)) << 4)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 256;
+    const int ntiles = s.Vp / 64;
+    const int nt0 = blockIdx.y * nt_per;
+    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
+    const int ntl = nt1 - nt0;
+    const int M = s.M, V = s.V;
+
+    if (wave >= 10) {
+        // -------------------------------------- store waves --------------------------------------
+        const int ls = tid - 640;
+        long long obase[16];
+        bool rok[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + (ls >> 3) + 16 * i;
+            rok[i] = m < M;
+            const int t = rok[i] ? m / s.B : 0, b = rok[i] ? m - t * s.B : 0;
+            obase[i] = (long long)t * sT + (long long)b * sB;
+        }
+        const int c = ls & 7;
+        __syncthreads();                                       // prologue barrier
+        for (int it = 0; it <= ntl; ++it) {
+            if (it >= 1) {
+                const unsigned char* buf = Os + ((it - 1) & 1) * OUTB;
+                const int n = (nt0 + it - 1) * BN + c * 8;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (ls >> 3) + 16 * i;
+                    const u32x4 v = *(const u32x4*)&buf[r * 128 + ((c ^ (r & 7)) << 4)];
+                    if (!rok[i] || n >= V) continue;
+                    bf16raw* p = dS + obase[i] + n;
+                    if (n + 8 <= V) {
+                        *(u32x4h*)p = v;
+                    } else {
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < V) p[e] = (bf16raw)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    if (wave >= 8) {
+        // -------------------------------------- loader waves -------------------------------------
+        const int lt = tid - 512;
+        int soff[SCH], goff[SCH];
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) {
+            const int g = lt + i * NLOAD;
+            const int vloc = g / CPR, ch = g - vloc * CPR;
+            // pair permutation of rs_gemm: LDS row rho holds W_emb row vloc
+            const int rho = (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3);
+            soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
+            goff[i] = g * 8;
+        }
+        u32x4 st[SCH];
+        auto load_tile = [&](int k) {                          // clamped, never skipped
+            const bf16raw* base = wemb + (long long)(nt0 + (k < ntl ? k : ntl - 1)) * BN * EP;
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
+        };
+        auto to_lds = [&](int k) {
+            unsigned char* buf = Bs + (k & 1) * TILEB;
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) *(u32x4*)&buf[soff[i]] = st[i];
+        };
+        load_tile(0);
+        to_lds(0);
+        load_tile(1);
+        __syncthreads();                                       // prologue barrier: tile 0 ready
+        for (int it = 0; it <= ntl; ++it) {
+            if (it + 1 < ntl) {
+                to_lds(it + 1);
+                load_tile(it + 2);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------------------------------- compute waves --------------------------------------
+    int mrow[2];
+    int rneed = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        mrow[tm] = m0 + wave * 32 + tm * 16 + (lane & 15);
+        if (mrow[tm] < M) rneed |= need[mrow[tm]];
+    }
+    const bool wave_any = __any(rneed != 0);
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(DX + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
+            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    int roff[4], rsw[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int rho = tn * 16 + (lane & 15);
+        roff[tn] = rho * ROWB;
+        rsw[tn] = (rho >> 1) & 7;
+    }
+    __syncthreads();                                           // prologue barrier
+    for (int it = 0; it <= ntl; ++it) {
+        if (it < ntl) {
+            const unsigned char* buf = Bs + (it & 1) * TILEB;
+            unsigned char* ob = Os + (it & 1) * OUTB;
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wave_any) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 bfr[4];
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        bfr[tn] = *(const bf16x8*)&buf[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int r = wave * 32 + tm * 16 + (lane & 15);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int c = 4 * pr + (lane >> 4);        // columns 32 pr + 8 (lane >> 4) .. + 7
+                    *(u32x4*)&ob[r * 128 + ((c ^ (r & 7)) << 4)] = pack_bf16x8(acc[tm][2 * pr], acc[tm][2 * pr + 1]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // K2a + K3 fast path (Ep == 32*KS, Ncat % 64 == 0): [G | Kk][m] = X[m] . Wcat^T + bcat.
 // Rows nobody reads (need == 0) are not written.
 template <int KS>

@@ -217,6 +217,16 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
             hipLaunchKernelGGL((k_softemb_bwd_ws<10, SRC_F32>), rs_grid, dim3(768), lds, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
         } else if (kind == SAD_SRC_BF16) {
             if (check_aligned(dsrc, 2, "dsrc")) return -1;
+            static const int ws_ver = getenv("SAD_K1B_WS") ? atoi(getenv("SAD_K1B_WS")) : 2;
+            if (ws_ver == 2) {      // loader + compute + store waves
+                constexpr size_t lds2 = 2 * 64 * 10 * 64 + 2 * 256 * 64 * 2;
+                static const hipError_t e3 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws2<10>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                (void)e3;
+                hipLaunchKernelGGL((k_softemb_bwd_ws2<10>), rs_grid, dim3(768), lds2, st, s, DX, need, wemb, (bf16raw*)dsrc, sT, sB, nt_per);
+                SAD_CHECK_LAUNCH("k_softemb_bwd_ws2");
+                return 0;
+            }
             static const hipError_t e2 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws<10, SRC_BF16>,
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             (void)e2;

@@ -130,6 +130,7 @@ int check_aligned(const void* p, size_t a, const char* name) {
 }
 
 typedef Cfg<128, 320, 2, 4, 2> CfgWideN;   // 512 threads; all of Ep=320 in one tile: S is read once
+typedef Cfg<64, 320, 2, 4, 2> CfgWideN64;  // K1 forward at small batches: half-height tiles, twice the workgroups
 typedef Cfg<128, 64, 2, 2, 2> CfgNarrowN;
 typedef Cfg<128, 128, 2, 2, 2> CfgSquare;
 typedef Cfg<64, 64, 2, 2, 2> CfgSmall;
@@ -179,13 +180,16 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
     float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
     const bool wide = s.Ep > 128;
+    const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles (measured: B=64 166 -> 93 us, B=1024 302 -> 417 us)
     if (kind == SAD_SRC_F32) {
         if (check_aligned(src, 4, "src")) return -1;
-        if (wide) launch_softemb_fwd<CfgWideN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
+        if (wide && small_m) launch_softemb_fwd<CfgWideN64, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
+        else if (wide) launch_softemb_fwd<CfgWideN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
         else launch_softemb_fwd<CfgNarrowN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
     } else if (kind == SAD_SRC_BF16) {
         if (check_aligned(src, 2, "src")) return -1;
-        if (wide) launch_softemb_fwd<CfgWideN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
+        if (wide && small_m) launch_softemb_fwd<CfgWideN64, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
+        else if (wide) launch_softemb_fwd<CfgWideN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
         else launch_softemb_fwd<CfgNarrowN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
     } else {
         return fail(-1, "soft-embedding stage needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);

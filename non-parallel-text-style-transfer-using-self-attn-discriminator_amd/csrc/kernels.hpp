@@ -170,6 +170,155 @@ __global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1 with LOADER and COMPUTE waves (large batches, Ep = 320): 768 threads per 128-row tile.
+//   waves 0-7  compute: fragments from LDS, 40 MFMAs per 64-deep k-tile, no vector-memory
+//              instruction until the epilogue;
+//   waves 8-11 loaders: S tile [128][64] (fp32 -> bf16 on the way, 2-/4-byte aligned rows) and
+//              W_emb^T tile [320][64] of k-tile k+1 into the spare LDS buffer while k is multiplied,
+//              two register sets so two k-tiles of loads are in flight.
+// One workgroup barrier per k-tile.  In the single-role kernel every wave alternates between
+// staging (global loads, LDS writes) and multiplying, and the phases add up (2 us per k-tile
+// against 0.55 us of MFMA).
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(768) void k_softemb_fwd_ws(Shape s, const void* __restrict__ src, long long sT, long long sB,
+                                                       const unsigned char* __restrict__ need,
+                                                       const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X) {
+    typedef Cfg<128, 320, 2, 4, 1> C;
+    typedef SoftRow<KIND> SR;
+    typedef typename SR::Elem Elem;
+    constexpr int ABYTES = 128 * 128, BBYTES = 320 * 128, BUF = ABYTES + BBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];     // 2 * BUF
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 128;
+    const int M = s.M, V = s.V, Vp = s.Vp;
+    {   // tiles nobody reads are skipped (every wave takes the same decision)
+        int any = 0;
+        for (int r = tid; r < 128; r += 768)
+            if (m0 + r < M && need[m0 + r]) any = 1;
+        if (!__syncthreads_or(any)) return;
+    }
+    const int nk = (V + 63) / 64;
+    if (wave >= 8) {
+        // ---------------------------------- loader waves ---------------------------------------
+        const int lt = tid - 512;
+        // chunk (lt + 256 i) = tile row lt/8 + 32 i, 16-byte chunk lt%8: the LDS swizzle depends on
+        // (row >> 1) & 7 only, so row + 32 i keeps it and every offset is base + i * constant.
+        const int r0 = lt >> 3, c0 = lt & 7;
+        const Elem* arow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + r0 + 32 * i;
+            arow[i] = nullptr;
+            if (m < M && need[m]) {
+                const int t = m / s.B, b = m - t * s.B;
+                arow[i] = (const Elem*)src + (long long)t * sT + (long long)b * sB + c0 * 8;
+            }
+        }
+        const int aoff0 = lds_off<C>(r0, c0) * 2, boff0 = ABYTES + aoff0;
+        const bf16raw* brow0 = wembT + (long long)r0 * Vp + c0 * 8;
+        const long long bstep = 32ll * Vp;
+        typename SR::Raw ra[2][4];
+        u32x4 rb[2][10];
+        const Elem* dummy = (const Elem*)src;
+        const int nkf = V / 64;                                // whole k-tiles: unguarded, branch-free loads
+        auto load_tile = [&](auto par, int kt) {               // clamped, never skipped: static operation counts
+            constexpr int P = decltype(par)::value;
+            const int k0 = (kt < nkf ? kt : nkf - 1) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_fast(arow[i], dummy, k0);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) rb[P][i] = *(const u32x4*)(brow0 + i * bstep + k0);
+        };
+        auto to_lds = [&](auto par, int kt) {
+            constexpr int P = decltype(par)::value;
+            unsigned char* buf = fw_lds + (kt & 1) * BUF;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)&buf[aoff0 + i * 4096] = typename SR::Cvt()(ra[P][i]);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) *(u32x4*)&buf[boff0 + i * 4096] = rb[P][i];
+        };
+        auto tail_to_lds = [&](int kt) {                       // the ragged last k-tile: element-guarded loads
+            unsigned char* buf = fw_lds + (kt & 1) * BUF;
+            const int k0 = kt * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(u32x4*)&buf[aoff0 + i * 4096] =
+                    typename SR::Cvt()(SR::load(arow[i] != nullptr ? arow[i] - c0 * 8 : nullptr, k0 + c0 * 8, V));
+#pragma unroll
+            for (int i = 0; i < 10; ++i) *(u32x4*)&buf[boff0 + i * 4096] = *(const u32x4*)(brow0 + i * bstep + k0);
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        int kt = 0;
+        if (nkf >= 1) {
+            load_tile(P0{}, 0);
+            load_tile(P1{}, 1);
+            to_lds(P0{}, 0);
+            load_tile(P0{}, 2);
+        } else {
+            tail_to_lds(0);
+        }
+        __syncthreads();                                       // k-tile 0 ready
+        // steady state, branch-free: while k-tiles kt, kt+1 are multiplied, kt+1 and kt+2 (whole tiles)
+        // go to LDS and kt+3, kt+4 are requested
+        for (; kt + 3 < nkf; kt += 2) {
+            to_lds(P1{}, kt + 1);
+            load_tile(P1{}, kt + 3);
+            __syncthreads();
+            to_lds(P0{}, kt + 2);
+            load_tile(P0{}, kt + 4);
+            __syncthreads();
+        }
+        // last few k-tiles: set (j+1)&1 still holds whole tile j+1; the ragged tail is loaded here
+        for (int j = kt; j < nk; ++j) {
+            if (j + 1 < nkf) {
+                if ((j + 1) & 1) to_lds(P1{}, j + 1);
+                else to_lds(P0{}, j + 1);
+            } else if (j + 1 < nk) {
+                tail_to_lds(j + 1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // -------------------------------------- compute waves ----------------------------------------
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    __syncthreads();                                           // k-tile 0 ready
+    for (int kt = 0; kt < nk; ++kt) {
+        const bf16raw* As = (const bf16raw*)(fw_lds + (kt & 1) * BUF);
+        const bf16raw* Bs = (const bf16raw*)(fw_lds + (kt & 1) * BUF + ABYTES);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[C::TM], bfr[C::TN];
+            const int ch = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) af[tm] = *(const bf16x8*)&As[lds_off<C>(frag_row<C>(wm, tm, lane), ch)];
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bfr[tn] = *(const bf16x8*)&Bs[lds_off<C>(wn * (C::BN / C::WN) + tn * 16 + (lane & 15), ch)];
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();                                       // k-tile kt consumed; kt+1 written by the loaders
+    }
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = frag_col<C>(wn, tn, lane);
+            if (m < M && n < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
+        }
+    }
+}
+
 // fp32 split-K accumulator -> bf16 operand buffer (8 elements per thread)
 __global__ void k_cvt_bf16(const float* __restrict__ src, bf16raw* __restrict__ dst, long long n8) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {

@@ -181,6 +181,25 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
     const bool wide = s.Ep > 128;
     const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles (measured: B=64 166 -> 93 us, B=1024 302 -> 417 us)
+    static const bool fwd_ws = getenv("SAD_K1F_WS") == nullptr || atoi(getenv("SAD_K1F_WS")) != 0;   // A/B switch
+    if (fwd_ws && s.Ep == 320 && !small_m && (kind == SAD_SRC_F32 || kind == SAD_SRC_BF16)) {
+        constexpr size_t lds = 2 * (128 * 128 + 320 * 128);
+        if (check_aligned(src, kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
+        const dim3 grid(ceil_div(s.M, 128));
+        if (kind == SAD_SRC_F32) {
+            static const hipError_t e1 = hipFuncSetAttribute((const void*)k_softemb_fwd_ws<SRC_F32>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)e1;
+            hipLaunchKernelGGL((k_softemb_fwd_ws<SRC_F32>), grid, dim3(768), lds, st, s, src, sT, sB, need, wembT, X);
+        } else {
+            static const hipError_t e2 = hipFuncSetAttribute((const void*)k_softemb_fwd_ws<SRC_BF16>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)e2;
+            hipLaunchKernelGGL((k_softemb_fwd_ws<SRC_BF16>), grid, dim3(768), lds, st, s, src, sT, sB, need, wembT, X);
+        }
+        SAD_CHECK_LAUNCH("k_softemb_fwd_ws");
+        return 0;
+    }
     if (kind == SAD_SRC_F32) {
         if (check_aligned(src, 4, "src")) return -1;
         if (wide && small_m) launch_softemb_fwd<CfgWideN64, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);

@@ -505,6 +505,25 @@ def test_persistent_recurrence_matches_per_step_kernels():
                 assert (got[name] - first[name]).abs().max().item() / scale < 1e-2, (B, T, H, rep, name)
 
 
+def test_long_sequences_vs_oracle():
+    """T = 100 at the shipped E/H (fast-path kernels, persistent recurrence with 100 hand-offs per
+    group, two sentence tiles, one of them partial): forward, dS and all parameter gradients vs the
+    fp64 oracle.  Errors of a bf16 recurrence grow with T; the stated tolerance still holds."""
+    V, E, H, B, T = 300, 300, 512, 150, 100
+    lengths = synth.make_lengths(B, T, seed=77)
+    params = synth.make_params(V, E, H, seed=8)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=2, kind="dense", time_major=False)
+    labels = synth.make_labels(B, seed=6)
+    mask = synth.transfer_mask(lengths, T)
+    out = run_sad(params, S, lengths, mask, labels, param_grads=True)
+    f, b = _oracle_grads(params, S, lengths, mask, labels)
+    errs = _grad_errors(out["grads"], b["grads"])
+    errs.update(logits=relerr(out["logits"], f["logits"]), weights=relerr(out["weights"], f["weights"]),
+                loss=relerr(out["loss"], f["loss"]), dS=relerr(out["dS"], b["dS"]))
+    _report("long sequences T=100", errs)
+    assert max(errs.values()) < BF16_TOL_BWD, errs
+
+
 def test_ragged_and_edge_shapes():
     """Edge cases: B=1, all lengths equal to T, len==2 rows (all-masked guard), a batch and T that
     are not multiples of any tile size, unsorted lengths given on the device (no host check)."""

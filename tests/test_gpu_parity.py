@@ -51,7 +51,9 @@ def _grad_errors(got, want):
         assert g is not None and g.shape == w.shape, k
         assert np.isfinite(g).all(), k
         # linear_attn.bias has an analytically zero gradient (softmax shift invariance): floor the scale
-        errs[k] = relerr(g, w, floor=1e-3)
+        # scale-aware error relative to the tensor's own largest entry; linear_attn.bias has an
+        # analytically zero gradient (softmax shift invariance), so only its absolute size is checked
+        errs[k] = relerr(g, w, floor=1e-3 if k == "linear_attn.bias" else 1e-12)
     return errs
 
 

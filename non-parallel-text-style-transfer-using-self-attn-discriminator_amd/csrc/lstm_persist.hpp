@@ -41,6 +41,18 @@ constexpr unsigned LP_OOB = 0x7ffffff0u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lp_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
+// Lanes l and l+16 (quad-rows 2p, 2p+1 of the wave) exchange halves: an even quad-row ends up with
+// {its own x, x of lane+16}, an odd one with {y of lane-16, its own y} (v_permlane16_swap: odd rows of
+// the first operand <-> even rows of the second).  Must be executed by both partners.
+__device__ __forceinline__ u32x4 lp_pair16(u32x2 x, u32x2 y) {
+    const auto s0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+// 16-byte agent-scope (sc1, write-through) store of handed-off payload.
+__device__ __forceinline__ void lp_store16_sc1(bf16raw* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
 }
@@ -212,8 +224,10 @@ __global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __
         }
         // ---- cell update; publish h_t first, the private stores (gates, c) after the signal -----------
         f32x4 gi[C::TM], gf[C::TM], gg[C::TM], go[C::TM];
+        u32x2 hp[C::TM];
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm) {
+            hp[tm] = u32x2{0u, 0u};
             if (!act[tm]) continue;
             const f32x4 pi = acc[tm][0] + pre[tm][0], pf = acc[tm][1] + pre[tm][1];
             const f32x4 pg = acc[tm][2] + pre[tm][2], po = acc[tm][3] + pre[tm][3];
@@ -229,10 +243,19 @@ __global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __
                 h[e] = go[tm][e] * tanhf_(c[e]);
             }
             creg[tm] = c;
-            const long long row = ((long long)t * B + brow[tm]) * 2 + dir;
-            const u32x2 hp = pack_bf16x4(h);
-            __hip_atomic_store((gu64*)&Hs[row * Hp + j], (unsigned long long)hp[0] | ((unsigned long long)hp[1] << 32),
-                               SAD_RLX_AGENT);
+            hp[tm] = pack_bf16x4(h);
+        }
+        {
+            // 16-byte sc1 stores (an 8-byte sc1 store is one fabric write of its own): lanes 16 apart
+            // hold neighbouring unit quads of the same sentence; after the row swap an even quad-row
+            // holds 8 consecutive units of row tm = 0, an odd one 8 consecutive units of row tm = 1.
+            static_assert(C::TM == 2, "publish pairs the wave's two row fragments");
+            const u32x4 v = lp_pair16(hp[0], hp[1]);
+            const int q = lane >> 4, tmq = q & 1;
+            if (tmq ? act[1] : act[0]) {
+                const long long row = ((long long)t * B + (tmq ? brow[1] : brow[0])) * 2 + dir;
+                lp_store16_sc1(&Hs[row * Hp + (col0 >> 6) * 16 + (q >> 1) * 8], v);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
         __syncthreads();
@@ -414,8 +437,12 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
             }
         }
         // ---- gate derivatives; publish dZ_t ----------------------------------------------------------
+        u32x2 pk[2][4];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pk[tn][g] = u32x2{0u, 0u};
         if (act) {
-            bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
                 const f32x4 dh = acc[tn] + edhf[tn];
@@ -435,12 +462,21 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                 dcreg[tn] = dcn;
                 const f32x4 zz[4] = {zi, zf, zg, zo};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const u32x2 pk = pack_bf16x4(zz[g]);
-                    __hip_atomic_store((gu64*)&zout[pcu[tn] + g * 16], (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 32),
-                                       SAD_RLX_AGENT);
-                }
+                for (int g = 0; g < 4; ++g) pk[tn][g] = pack_bf16x4(zz[g]);
             }
+        }
+        {
+            // 16-byte sc1 stores: lanes 16 apart hold neighbouring unit quads of the same sentence; after
+            // the row swap an even quad-row holds 8 consecutive units of gate 2p, an odd one of gate 2p+1.
+            bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+            const int q = lane >> 4;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const u32x4 v = lp_pair16(pk[tn][2 * p2], pk[tn][2 * p2 + 1]);
+                    if (act) lp_store16_sc1(&zout[(pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8], v);
+                }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
         __syncthreads();

@@ -291,14 +291,38 @@ namespace sad {
 // accumulator layout (lane = sentence, 4 consecutive units) is exactly the epilogue's.
 // Hand-off protocol: as in k_lstm_fwd_persist.
 // ------------------------------------------------------------------------------------------------
-constexpr int LB_BM = 128, LB_BN = 32, LB_SG_MAX = 16;       // Gp <= 128 * LB_SG_MAX
+#ifndef SAD_LB_NS
+#define SAD_LB_NS 3
+#endif
+constexpr int LB_BM = 128, LB_BN = 32, LB_SG_MAX = 16, LB_NS = SAD_LB_NS;       // Gp <= 128 * LB_SG_MAX
 
 __host__ __device__ inline size_t lstm_bwd_persist_lds_bytes(int Gp) { return (size_t)LB_BN * Gp * 2 + 16; }
+// Hand-off image of dZ between the workgroups of a group, two step parities: laid out so that the 16
+// lanes of a quarter wave (16 sentences, one 8-column chunk = one MFMA fragment piece each) touch 256
+// contiguous bytes -- fragments loaded straight from the row-major DZ touched 16 cache lines per
+// quarter wave and ran at ~17 B/clk per CU.
+__host__ __device__ inline size_t lstm_bwd_xchg_bytes(int B, int Gp) {
+    return (size_t)2 * 2 * ((B + LB_BM - 1) / LB_BM * LB_BM) * Gp * 2;
+}
 
+#ifdef SAD_LB_PROF
+// debug build only: phase timers (100 MHz wall clock) of one workgroup -> the free words after the timeout words
+#define LB_PROF_DECL unsigned long long pt[7] = {0,0,0,0,0,0,0}, pa[7] = {0,0,0,0,0,0,0}; unsigned psteps = 0;
+#define LB_PROF_T(i) pt[i] = wall_clock64();
+#define LB_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0]), "v"(acc[1][0])); }
+#define LB_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; }
+#define LB_PROF_OUT if (tid == 0 && group == SAD_LB_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)groups * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; }
+#else
+#define LB_PROF_DECL
+#define LB_PROF_T(i)
+#define LB_PROF_ACC
+#define LB_PROF_END
+#define LB_PROF_OUT
+#endif
 __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __restrict__ lens,
                                                          const bf16raw* __restrict__ whhT, const float* __restrict__ G,
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
-                                                         bf16raw* DZ, unsigned* sync) {
+                                                         bf16raw* DZ, bf16raw* DZX, unsigned* sync) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
     bf16raw* Wl = (bf16raw*)lp_lds;                                  // [32][Gp], chunk-swizzled
@@ -357,8 +381,13 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         }
     }
     const int nsg = Gp / 128;                                // fragment sets of 4 x 32 k
+    // hand-off image of dZ (see lstm_bwd_xchg_bytes): [parity][dir][16-sentence block][8-column chunk][16][8]
+    const int sblocks = rtiles * (LB_BM / 16);
+    const size_t xpar = (size_t)2 * sblocks * Gp * 16;       // elements of one parity
+    const unsigned xrow = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave) * (Gp / 8) * 128 + (lane & 15) * 8);
     unsigned done = 0;
     bool dead = false;
+    LB_PROF_DECL
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? step : T - 1 - step;             // reverse of the forward order
@@ -385,6 +414,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         }
         f32x4 acc[2];
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        LB_PROF_T(0)
         if (done > 0) {
             if (tid == 0 && !dead) {
                 const unsigned target = done * (unsigned)ctiles;
@@ -398,15 +428,17 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                     }
                 }
             }
+            LB_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();
+            LB_PROF_T(2)
             // ---- dh = dZ_{tn} . W_hh for this wave's 16 sentences ------------------------------------
             const bool rowok = len > tn_ && act;
-            const __amdgpu_buffer_rsrc_t rs = lp_rsrc(DZ + (long long)tn_ * B * Ncat, (unsigned)B * (unsigned)Ncat * 2u);
-            const unsigned voff = rowok ? (unsigned)(b * Ncat + dir * Gp + (lane >> 4) * 8) * 2u : LP_OOB;
+            const __amdgpu_buffer_rsrc_t rs = lp_rsrc(DZX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
+            const unsigned voff = rowok ? (xrow + (unsigned)(lane >> 4) * 128u) * 2u : LP_OOB;
             auto load_set = [&](int sg, u32x4 (&f)[4]) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f[q] = lp_load16_sc1(rs, sg < nsg ? voff + (unsigned)(sg * 128 + q * 32) * 2u : LP_OOB);
+                for (int q = 0; q < 4; ++q) f[q] = lp_load16_sc1(rs, sg < nsg ? voff + (unsigned)(sg * 16 + q * 4) * 256u : LP_OOB);
             };
             auto mma_set = [&](int sg, const u32x4 (&f)[4]) {
                 if (sg >= nsg) return;
@@ -422,20 +454,22 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                     }
                 }
             };
-            u32x4 f0[4], f1[4], f2[4];
-            load_set(0, f0);
-            load_set(1, f1);
-            load_set(2, f2);
+            // LB_NS fragment sets (LB_NS x 4 KB per wave) in flight: the loads come through the fabric
+            // (sc1), so the bytes in flight per CU set the rate.  Sets beyond nsg are OOB loads (zeros).
+            u32x4 f[LB_NS][4];
+#pragma unroll
+            for (int i = 0; i < LB_NS; ++i) load_set(i, f[i]);
 #pragma nounroll
-            for (int sg = 0; sg < nsg; sg += 3) {
-                mma_set(sg, f0);
-                load_set(sg + 3, f0);
-                mma_set(sg + 1, f1);
-                load_set(sg + 4, f1);
-                mma_set(sg + 2, f2);
-                load_set(sg + 5, f2);
+            for (int sg = 0; sg < nsg; sg += LB_NS) {
+#pragma unroll
+                for (int i = 0; i < LB_NS; ++i) {
+                    mma_set(sg + i, f[i]);
+                    load_set(sg + LB_NS + i, f[i]);
+                }
             }
         }
+        LB_PROF_ACC
+        LB_PROF_T(3)
         // ---- gate derivatives; publish dZ_t ----------------------------------------------------------
         u32x2 pk[2][4];
 #pragma unroll
@@ -465,24 +499,42 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                 for (int g = 0; g < 4; ++g) pk[tn][g] = pack_bf16x4(zz[g]);
             }
         }
+        // 16-byte pieces: lanes 16 apart hold neighbouring unit quads of the same sentence; after the row
+        // swap an even quad-row holds 8 consecutive units of gate 2p, an odd one of gate 2p+1.  A wave's
+        // store covers 4 consecutive chunks x 16 sentences = 1 KB of the hand-off image (sc1).
+        u32x4 pv[2][2];
         {
-            // 16-byte sc1 stores: lanes 16 apart hold neighbouring unit quads of the same sentence; after
-            // the row swap an even quad-row holds 8 consecutive units of gate 2p, an odd one of gate 2p+1.
-            bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+            bf16raw* xout = DZX + (done & 1) * xpar + xrow;
             const int q = lane >> 4;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
-                    const u32x4 v = lp_pair16(pk[tn][2 * p2], pk[tn][2 * p2 + 1]);
-                    if (act) lp_store16_sc1(&zout[(pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8], v);
+                    pv[tn][p2] = lp_pair16(pk[tn][2 * p2], pk[tn][2 * p2 + 1]);
+                    const int col = (pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8;
+                    if (act) lp_store16_sc1(&xout[(col >> 3) * 128], pv[tn][p2]);
                 }
         }
+        LB_PROF_T(4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
+        LB_PROF_T(5)
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
         ++done;
+        if (act) {
+            // row-major copy for the kernels after the recurrence: not part of the hand-off, plain stores
+            bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+            const int q = lane >> 4;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2)
+                    *(u32x4*)&zout[(pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8] = pv[tn][p2];
+        }
+        LB_PROF_T(6)
+        LB_PROF_END
     }
+    LB_PROF_OUT
 }
 
 }  // namespace sad

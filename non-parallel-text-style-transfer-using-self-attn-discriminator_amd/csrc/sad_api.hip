@@ -93,6 +93,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_ROWS] = M * 3 * 4;
     w.bytes[SAD_WS_NROWS] = 4 * 4;
     w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
+    w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -629,7 +630,7 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
         // counters only: the timeout words behind them keep what the forward left
         (void)hipMemsetAsync(sync, 0, (size_t)2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH * 4, st);
         hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), st, s, lens,
-                           at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, sync);
+                           at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, at<bf16raw>(ws, wl.off[SAD_WS_DZX]), sync);
     } else {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;

@@ -319,6 +319,231 @@ __global__ __launch_bounds__(768) void k_softemb_fwd_ws(Shape s, const void* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1, three wave roles (large batches, Ep = 320): the two operand streams have different latencies
+// (S comes from HBM, ~2.3 us under load; W_emb^T from L2), and vmcnt retires in order inside a wave,
+// so one loader wave cannot keep different depths in flight for them.
+//   waves 0-7   compute (as in k_softemb_fwd_ws);
+//   waves 8-11  S loaders: register-staged (dtype conversion, 2-/4-byte aligned rows), D k-tiles of
+//               loads in flight (4 for bf16 S, 2 for fp32 S), two LDS stages;
+//   waves 12-15 W loaders: LDS-direct loads (global_load_lds_dwordx4, no registers), three LDS
+//               stages, two k-tiles in flight, own vmcnt counting and raw barriers.  The LDS image is
+//               lane-linear per instruction (8 rows x 128 B); the chunk swizzle is applied to the
+//               SOURCE address.
+// One workgroup barrier per k-tile, 1 + nk barriers in every role.
+// Measured (cfg3, tools/k1prof.py): the W loaders spend 0.8 us per k-tile inside the issue of their
+// LDS-direct loads whether 2 or 4 waves share them -- the CU takes in its 56 KB per k-tile at
+// ~50-70 GB/s (the per-CU L2 read rate), which is what bounds this kernel now (compute: 0.47 us).
+// ------------------------------------------------------------------------------------------------
+#ifdef SAD_K1F_PROF
+// debug build only: phase timers of one workgroup, printed by one lane per role
+#define K1P_DECL long long pt_[4] = {0, 0, 0, 0}, pa_[4] = {0, 0, 0, 0}; int pn_ = 0;
+#define K1P_T(i) pt_[i] = wall_clock64();
+#define K1P_ACC { for (int i_ = 1; i_ < 4; ++i_) pa_[i_] += pt_[i_] - pt_[i_ - 1]; ++pn_; }
+#define K1P_MFMA { float t_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(t_) : "v"(acc[0][0][0]), "v"(acc[C::TM - 1][C::TN - 1][0])); }
+#define K1P_OUT(what) if (blockIdx.x == SAD_K1F_PROF && lane == 0 && (wave == 0 || wave == 8 || wave == 12)) printf("%s: n=%d  %.3f %.3f %.3f us per k-tile\n", what, pn_, pa_[1] / 100.0 / pn_, pa_[2] / 100.0 / pn_, pa_[3] / 100.0 / pn_);
+#else
+#define K1P_DECL
+#define K1P_T(i)
+#define K1P_ACC
+#define K1P_MFMA
+#define K1P_OUT(what)
+#endif
+#ifndef SAD_K1F_D
+#define SAD_K1F_D 4
+#endif
+typedef __attribute__((address_space(1))) const void gmem_cv;
+typedef __attribute__((address_space(3))) void lds_v;
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_softemb_fwd_ws3(Shape s, const void* __restrict__ src, long long sT, long long sB,
+                                                        const unsigned char* __restrict__ need,
+                                                        const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X) {
+    typedef Cfg<128, 320, 2, 4, 1> C;
+    typedef SoftRow<KIND> SR;
+    typedef typename SR::Elem Elem;
+    constexpr int ABYTES = 128 * 128, BBYTES = 320 * 128, BOFF = 2 * ABYTES;   // LDS: A0 A1 B0 B1 B2
+    constexpr int D = sizeof(typename SR::Raw) > 16 ? 2 : SAD_K1F_D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 128;
+    const int M = s.M, V = s.V, Vp = s.Vp;
+    {   // tiles nobody reads are skipped (every wave takes the same decision)
+        int any = 0;
+        for (int r = tid; r < 128; r += 1024)
+            if (m0 + r < M && need[m0 + r]) any = 1;
+        if (!__syncthreads_or(any)) return;
+    }
+    const int nk = (V + 63) / 64;
+    if (wave >= 12) {
+        // ---------------------------------- W loader waves -------------------------------------
+        const int ww = wave - 12, r = lane >> 3, sl = lane & 7;
+        K1P_DECL
+        // instruction i covers tile rows R0 = (10 ww + i) * 8 .. + 7; lane -> row R0 + r, LDS slot sl,
+        // which holds global chunk sl ^ ((row >> 1) & 7); (R0 >> 1) & 7 is 0 for even i, 4 for odd i
+        const bf16raw* be = wembT + (long long)(ww * 80 + r) * Vp + ((sl ^ (r >> 1)) << 3);
+        const bf16raw* bo = wembT + (long long)(ww * 80 + 8 + r) * Vp + ((sl ^ (4 + (r >> 1))) << 3);
+        const long long step2 = 16ll * Vp;
+        auto issue = [&](int kt, int st) {
+            unsigned char* dst = fw_lds + BOFF + st * BBYTES + ww * (80 * 128);
+            const int k0 = kt * 64;
+#pragma unroll
+            for (int y = 0; y < 5; ++y) {
+                __builtin_amdgcn_global_load_lds((gmem_cv*)(be + y * step2 + k0), (lds_v*)(dst + (2 * y) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gmem_cv*)(bo + y * step2 + k0), (lds_v*)(dst + (2 * y + 1) * 1024), 16, 0, 0);
+            }
+        };
+        issue(0, 0);
+        if (nk > 1) {
+            issue(1, 1);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                          // k-tile 0 ready
+        int st2 = 2;                                           // stage of k-tile kt + 2
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage (kt + 2) % 3 was last read in iteration kt - 1: free
+            K1P_T(0)
+            if (kt + 2 < nk) {
+                issue(kt + 2, st2);
+                K1P_T(1)
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // k-tile kt + 1 has landed
+            } else {
+                K1P_T(1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            K1P_T(2)
+            st2 = st2 == 2 ? 0 : st2 + 1;
+            __builtin_amdgcn_s_barrier();
+            K1P_T(3)
+            K1P_ACC
+        }
+        K1P_OUT("W loader: issue, wait, barrier")
+        return;
+    }
+    if (wave >= 8) {
+        // ---------------------------------- S loader waves -------------------------------------
+        const int lt = tid - 512;                              // 0..255: tile row lt/8 + 32 i, 16-byte chunk lt%8
+        K1P_DECL
+        const int r0 = lt >> 3, c0 = lt & 7;
+        const Elem* arow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + r0 + 32 * i;
+            arow[i] = nullptr;
+            if (m < M && need[m]) {
+                const int t = m / s.B, b = m - t * s.B;
+                arow[i] = (const Elem*)src + (long long)t * sT + (long long)b * sB + c0 * 8;
+            }
+        }
+        const int aoff0 = lds_off<C>(r0, c0) * 2;              // row + 32 i keeps the swizzle: + i * 4096 bytes
+        typename SR::Raw ra[D][4];
+        const Elem* dummy = (const Elem*)src;
+        const int nkf = V / 64;                                // whole k-tiles: unguarded, branch-free loads
+        auto load_tile = [&](auto par, int kt) {               // clamped, never skipped: static operation counts
+            constexpr int P = decltype(par)::value;
+            const int k0 = (kt < nkf ? kt : nkf - 1) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_fast(arow[i], dummy, k0);
+        };
+        auto to_lds = [&](auto par, int kt) {
+            constexpr int P = decltype(par)::value;
+            unsigned char* buf = fw_lds + (kt & 1) * ABYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)&buf[aoff0 + i * 4096] = typename SR::Cvt()(ra[P][i]);
+        };
+        auto tail_to_lds = [&](int kt) {                       // the ragged last k-tile: element-guarded loads
+            unsigned char* buf = fw_lds + (kt & 1) * ABYTES;
+            const int k0 = kt * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(u32x4*)&buf[aoff0 + i * 4096] =
+                    typename SR::Cvt()(SR::load(arow[i] != nullptr ? arow[i] - c0 * 8 : nullptr, k0 + c0 * 8, V));
+        };
+        int kt = 0;
+        if (nkf >= 1) {
+            static_for<D>([&](auto d) { load_tile(d, decltype(d)::value); });
+            to_lds(std::integral_constant<int, 0>{}, 0);
+            load_tile(std::integral_constant<int, 0>{}, D);
+        } else {
+            tail_to_lds(0);
+        }
+        __syncthreads();                                       // k-tile 0 ready
+        // steady state, branch-free: iteration j writes whole k-tile j + 1 (set (j+1) % D) and requests j + 1 + D
+        for (; kt + D < nkf; kt += D) {
+            static_for<D>([&](auto u) {
+                constexpr int U = decltype(u)::value;
+                using P = std::integral_constant<int, (U + 1) % D>;
+                K1P_T(0)
+                to_lds(P{}, kt + U + 1);
+                K1P_T(1)
+                load_tile(P{}, kt + U + 1 + D);
+                K1P_T(2)
+                __syncthreads();
+                K1P_T(3)
+                K1P_ACC
+            });
+        }
+        for (int j = kt; j < nk; ++j) {
+            if (j + 1 < nkf) {
+                static_for<D>([&](auto d) {
+                    if ((j + 1) % D == decltype(d)::value) to_lds(d, j + 1);
+                });
+            } else if (j + 1 < nk) {
+                tail_to_lds(j + 1);
+            }
+            __syncthreads();
+        }
+        K1P_OUT("S loader: to_lds (wait + write), issue, barrier")
+        return;
+    }
+    // -------------------------------------- compute waves ----------------------------------------
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    f32x4 acc[C::TM][C::TN];
+    zero_acc<C>(acc);
+    __syncthreads();                                           // k-tile 0 ready
+    int st = 0;
+    K1P_DECL
+    for (int kt = 0; kt < nk; ++kt) {
+        K1P_T(0)
+        K1P_T(1)
+        const bf16raw* As = (const bf16raw*)(fw_lds + (kt & 1) * ABYTES);
+        const bf16raw* Bs = (const bf16raw*)(fw_lds + BOFF + st * BBYTES);
+        st = st == 2 ? 0 : st + 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[C::TM], bfr[C::TN];
+            const int ch = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) af[tm] = *(const bf16x8*)&As[lds_off<C>(frag_row<C>(wm, tm, lane), ch)];
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bfr[tn] = *(const bf16x8*)&Bs[lds_off<C>(wn * (C::BN / C::WN) + tn * 16 + (lane & 15), ch)];
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
+        }
+        K1P_MFMA
+        K1P_T(2)
+        __syncthreads();                                       // k-tile kt consumed; kt+1 written by the loaders
+        K1P_T(3)
+        K1P_ACC
+    }
+    K1P_OUT("compute: -, reads + MFMA, barrier")
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = frag_col<C>(wn, tn, lane);
+            if (m < M && n < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
+        }
+    }
+}
+
 // fp32 split-K accumulator -> bf16 operand buffer (8 elements per thread)
 __global__ void k_cvt_bf16(const float* __restrict__ src, bf16raw* __restrict__ dst, long long n8) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {

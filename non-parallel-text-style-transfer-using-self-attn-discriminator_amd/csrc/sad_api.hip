@@ -183,21 +183,25 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const bool wide = s.Ep > 128;
     const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles (measured: B=64 166 -> 93 us, B=1024 302 -> 417 us)
     static const bool fwd_ws = getenv("SAD_K1F_WS") == nullptr || atoi(getenv("SAD_K1F_WS")) != 0;   // A/B switch
+    static const int fwd_ws_kind = getenv("SAD_K1F_WS") == nullptr ? 3 : atoi(getenv("SAD_K1F_WS"));
     if (fwd_ws && s.Ep == 320 && !small_m && (kind == SAD_SRC_F32 || kind == SAD_SRC_BF16)) {
-        constexpr size_t lds = 2 * (128 * 128 + 320 * 128);
         if (check_aligned(src, kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
         const dim3 grid(ceil_div(s.M, 128));
-        if (kind == SAD_SRC_F32) {
-            static const hipError_t e1 = hipFuncSetAttribute((const void*)k_softemb_fwd_ws<SRC_F32>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)e1;
-            hipLaunchKernelGGL((k_softemb_fwd_ws<SRC_F32>), grid, dim3(768), lds, st, s, src, sT, sB, need, wembT, X);
+#define SAD_K1F_LAUNCH(KERNEL, LDS, THREADS)                                                                             \
+    {                                                                                                            \
+        static const hipError_t e_ = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        (void)e_;                                                                                                \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), LDS, st, s, src, sT, sB, need, wembT, X);                    \
+    }
+        constexpr size_t lds2 = 2 * (128 * 128 + 320 * 128), lds3 = 2 * 128 * 128 + 3 * 320 * 128;
+        if (fwd_ws_kind == 3) {     // S and W loader waves apart (deep S prefetch, LDS-direct W)
+            if (kind == SAD_SRC_F32) SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_F32>, lds3, 1024)
+            else SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_BF16>, lds3, 1024)
         } else {
-            static const hipError_t e2 = hipFuncSetAttribute((const void*)k_softemb_fwd_ws<SRC_BF16>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)e2;
-            hipLaunchKernelGGL((k_softemb_fwd_ws<SRC_BF16>), grid, dim3(768), lds, st, s, src, sT, sB, need, wembT, X);
+            if (kind == SAD_SRC_F32) SAD_K1F_LAUNCH(k_softemb_fwd_ws<SRC_F32>, lds2, 768)
+            else SAD_K1F_LAUNCH(k_softemb_fwd_ws<SRC_BF16>, lds2, 768)
         }
+#undef SAD_K1F_LAUNCH
         SAD_CHECK_LAUNCH("k_softemb_fwd_ws");
         return 0;
     }

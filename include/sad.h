@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 111 /* 0.1.1 */
+#define SAD_VERSION 112 /* 0.1.1 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -149,6 +149,7 @@ enum sad_ws_field {
     SAD_WS_SYNC,     /* u32: hand-off counters of the persistent recurrence (one 128-B line per sentence
                         tile and direction), then the timeout word (non-zero = a wait timed out) */
     SAD_WS_DZX,      /* bf16 [2][2][B/16][Gp/8][16][8] hand-off image of dZ inside the persistent BPTT */
+    SAD_WS_HX,       /* bf16 [2][2][B/16][Hp/8][16][8] hand-off image of h inside the persistent recurrence */
     SAD_WS_NFIELDS
 };
 

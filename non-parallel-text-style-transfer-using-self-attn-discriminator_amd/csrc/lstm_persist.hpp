@@ -279,6 +279,232 @@ __global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __
 namespace sad {
 
 // ------------------------------------------------------------------------------------------------
+// K2b, second form: HALF-WIDTH workgroups, TWO per CU.
+// One step of the recurrence is a chain of waits (hand-off visible -> h loads -> MFMA -> cell update
+// -> write-through stores drained -> signal); with one workgroup per CU the CU idles through most of
+// it (13.4 us per step at cfg3 for 0.9 us of MFMA).  Here a workgroup has 256 threads and owns 128
+// sentences x 64 permuted gate columns (16 units) of one direction; its W_hh slice is 64 KB, so two
+// workgroups (of any two groups) share a CU and one computes while the other waits.
+//   * wave w owns sentences 32w..32w+31 (two MFMA row fragments): B fragments from LDS feed two
+//     MFMAs each, A fragments (h_{t-1}) come straight from global memory -- no LDS staging and no
+//     barrier inside the K loop;
+//   * h is handed over through an image in MFMA-fragment order (lstm_fwd_xchg_bytes), two step
+//     parities, like dZ in the BPTT: the 16 lanes of a quarter wave read 256 contiguous bytes;
+//   * the row-major Hs (hidden bridge, weight gradients), the activated gates and c are written with
+//     plain stores after the signal.
+// Hand-off protocol: as in k_lstm_fwd_persist (16-byte sc1 stores, drain, barrier, counter add;
+// one-lane bounded poll, barrier, 16-byte sc1 loads).
+// ------------------------------------------------------------------------------------------------
+#ifndef SAD_LF_NS
+#define SAD_LF_NS 2
+#endif
+constexpr int LF_BM = 128, LF_BN = 64, LF_KS_MAX = 16, LF_NS = SAD_LF_NS;   // Hp <= 32 * LF_KS_MAX
+
+__host__ __device__ inline size_t lstm_fwd2_lds_bytes(int Hp) { return (size_t)LF_BN * Hp * 2 + 16; }
+__host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
+    return (size_t)2 * 2 * ((B + LF_BM - 1) / LF_BM * LF_BM) * Hp * 2;
+}
+
+__global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int* __restrict__ lens,
+                                                          const bf16raw* __restrict__ whh, float* __restrict__ G,
+                                                          float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
+                                                          unsigned* sync) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
+    const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
+    bf16raw* Wl = (bf16raw*)lp_lds;                          // [64][Hp], chunk-swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ctiles = Gp / LF_BN, rtiles = (B + LF_BM - 1) / LF_BM, groups = rtiles * 2;
+    int group, ct;
+    if (groups % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only): keep a group on one XCD
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        group = xcd + 8 * (slot / ctiles);
+        ct = slot % ctiles;
+    } else {
+        group = blockIdx.x / ctiles;
+        ct = blockIdx.x % ctiles;
+    }
+    const int dir = group & 1, b0 = (group >> 1) * LF_BM, n0 = ct * LF_BN;
+    gu32* counter = (gu32*)(sync + (size_t)group * LP_SYNC_PITCH);
+    gu32* errword = (gu32*)(sync + (size_t)groups * LP_SYNC_PITCH);
+    const int cpr = Hp / 8;                                  // 16-byte chunks per W row
+    const int cmask = (cpr % 16 == 0) ? 15 : 3;
+    {
+        const bf16raw* w = whh + ((long long)dir * Gp + n0) * Hp;
+        for (int idx = tid; idx < LF_BN * cpr; idx += 256) {
+            const int r = idx / cpr, c = idx - r * cpr;
+            *(u32x4*)(Wl + (long long)r * Hp + lp_wswz(r, c, cmask) * 8) = *(const u32x4*)(w + (long long)r * Hp + c * 8);
+        }
+    }
+    int maxlen = 0;
+    {
+        int* red_max = (int*)(lp_lds + (size_t)LF_BN * Hp * 2);
+        if (tid == 0) *red_max = 0;
+        __syncthreads();
+        if (tid < LF_BM && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
+        __syncthreads();
+        maxlen = *red_max;
+    }
+    const int q = lane >> 4, u4 = q * 4;
+    const int j = ct * 16 + u4;                              // first of this lane's 4 hidden units
+    const int sblocks = rtiles * (LF_BM / 16);
+    const size_t xpar = (size_t)2 * sblocks * Hp * 16;       // elements of one parity of the image
+    int brow[2], blen[2];
+    unsigned xrow[2];                                        // image offset (elements) of this lane's sentence, chunk 0
+    f32x4 creg[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        brow[tm] = b0 + wave * 32 + tm * 16 + (lane & 15);
+        blen[tm] = brow[tm] < B ? lens[brow[tm]] : 0;
+        creg[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        xrow[tm] = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave * 2 + tm) * cpr * 128 + (lane & 15) * 8);
+    }
+    const int nks = Hp / 32;
+    unsigned done = 0;
+    bool dead = false;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        if (!(maxlen > t)) continue;                         // group-uniform: no sentence of the tile is alive
+        const int tp = dir ? t + 1 : t - 1;
+        f32x4 pre[2][4];
+        bool act[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            act[tm] = blen[tm] > t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (act[tm]) {
+                const float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) pre[tm][gq] = *(const f32x4*)(g + 16 * gq);
+            }
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (done > 0) {
+            if (tid == 0 && !dead) {
+                const unsigned target = done * (unsigned)ctiles;
+                unsigned spins = 0;
+                while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > LP_SPIN_LIMIT) {
+                        __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
+                        dead = true;
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
+            __syncthreads();
+            // ---- h_{tp} of this wave's 32 sentences: LF_NS sets of 4 k-steps (4 KB per wave each) in flight,
+            //      16-byte sc1 loads straight into MFMA fragment registers; gates += h_{tp} . W_hh^T
+            const __amdgpu_buffer_rsrc_t rs = lp_rsrc(HX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
+            unsigned voff[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) voff[tm] = blen[tm] > tp ? (xrow[tm] + (unsigned)q * 128u) * 2u : LP_OOB;
+            u32x4 a[LF_NS][2][4];
+            auto load_set = [&](auto slot, int sg) {
+                constexpr int S = decltype(slot)::value;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        a[S][tm][kk] = lp_load16_sc1(rs, sg * 4 + kk < nks ? voff[tm] + (unsigned)(sg * 4 + kk) * 1024u : LP_OOB);
+            };
+            auto mma_set = [&](auto slot, int sg) {
+                constexpr int S = decltype(slot)::value;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (sg * 4 + kk < nks) {
+                        const int ch = (sg * 4 + kk) * 4 + q;
+                        bf16x8 bfr[4];
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn) {
+                            const int col = tn * 16 + (lane & 15);
+                            bfr[tn] = *(const bf16x8*)(Wl + (long long)col * Hp + lp_wswz(col, ch, cmask) * 8);
+                        }
+#pragma unroll
+                        for (int tm = 0; tm < 2; ++tm) {
+                            const bf16x8 af = __builtin_bit_cast(bf16x8, a[S][tm][kk]);
+#pragma unroll
+                            for (int tn = 0; tn < 4; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af, acc[tm][tn], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            // a real loop (not unrolled): straight-line code lets the scheduler hoist every LDS fragment
+            // read to the top and spill
+            const int nsets = (nks + 3) / 4;
+#pragma unroll
+            for (int i = 0; i < LF_NS; ++i) static_for<LF_NS>([&](auto sl) { if (decltype(sl)::value == i) load_set(sl, i); });
+#pragma nounroll
+            for (int sg = 0; sg < nsets; sg += LF_NS) {
+                static_for<LF_NS>([&](auto sl) {
+                    constexpr int I = decltype(sl)::value;
+                    mma_set(sl, sg + I);
+                    load_set(sl, sg + LF_NS + I);
+                });
+            }
+        }
+        // ---- cell update; publish h_t first, the private stores (Hs, gates, c) after the signal -------
+        f32x4 gi[2], gf[2], gg[2], go[2];
+        u32x2 hp[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            hp[tm] = u32x2{0u, 0u};
+            if (!act[tm]) continue;
+            const f32x4 pi = acc[tm][0] + pre[tm][0], pf = acc[tm][1] + pre[tm][1];
+            const f32x4 pg = acc[tm][2] + pre[tm][2], po = acc[tm][3] + pre[tm][3];
+            const f32x4 cprev = creg[tm];     // still zero at a sentence's first step in this direction
+            f32x4 c, h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gi[tm][e] = sigmoidf_(pi[e]);
+                gf[tm][e] = sigmoidf_(pf[e]);
+                gg[tm][e] = tanhf_(pg[e]);
+                go[tm][e] = sigmoidf_(po[e]);
+                c[e] = gf[tm][e] * cprev[e] + gi[tm][e] * gg[tm][e];
+                h[e] = go[tm][e] * tanhf_(c[e]);
+            }
+            creg[tm] = c;
+            hp[tm] = pack_bf16x4(h);
+        }
+        // lanes 16 apart hold neighbouring unit quads of the same sentence: after the row swap an even
+        // quad-row holds 8 consecutive units of row fragment 0, an odd one of row fragment 1
+        const u32x4 hv = lp_pair16(hp[0], hp[1]);
+        const int tmq = q & 1;
+        const bool actq = tmq ? act[1] : act[0];
+        if (actq) lp_store16_sc1(HX + (done & 1) * xpar + (tmq ? xrow[1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u, hv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
+        ++done;
+        if (actq) {
+            const long long row = ((long long)t * B + (tmq ? brow[1] : brow[0])) * 2 + dir;
+            *(u32x4*)&Hs[row * Hp + ct * 16 + (q >> 1) * 8] = hv;
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            if (!act[tm]) continue;
+            float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
+            *(f32x4*)(g + 0) = gi[tm];
+            *(f32x4*)(g + 16) = gf[tm];
+            *(f32x4*)(g + 32) = gg[tm];
+            *(f32x4*)(g + 48) = go[tm];
+            *(f32x4*)&Cs[(((long long)t * B + brow[tm]) * 2 + dir) * Hp + j] = creg[tm];
+        }
+    }
+}
+
+}  // namespace sad
+
+namespace sad {
+
+// ------------------------------------------------------------------------------------------------
 // Persistent BPTT (K2'): ONE launch for all T steps of both directions, frozen weights.
 //   dh_t = dZ_{next} . W_hh (+ d h_final at a sentence's last step), gate derivatives -> dZ_t.
 // A workgroup owns 128 sentences x 32 hidden units of one direction; its W_hh^T slice [32][Gp] bf16

@@ -94,6 +94,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_NROWS] = 4 * 4;
     w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
     w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
+    w.bytes[SAD_WS_HX] = lstm_fwd_xchg_bytes(s.B, s.Hp);
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -300,20 +301,28 @@ void launch_wg(K kernel, dim3 grid, hipStream_t st, Args... args) {
 
 // The persistent recurrences need every workgroup co-resident (they wait for each other): the grid
 // must fit the device at the kernel's own occupancy.  SAD_NO_PERSIST=1 forces the per-step kernels.
-bool persist_fits(const void* kernel, size_t lds, int grid) {
+bool persist_fits(const void* kernel, size_t lds, int grid, int threads = 512) {
     const char* env = getenv("SAD_NO_PERSIST");      // read per call: tests switch paths in-process
     if (env != nullptr && atoi(env) != 0) return false;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return false;
     return per_cu >= 1 && grid <= per_cu * cus;
 }
 bool lstm_persist_fits(const Shape& s, int* grid) {
     if (s.Hp > 64 * LP_KT_MAX || s.Gp % LP_BN != 0 || (long long)s.B * s.Hp * 4 >= (1ll << 31)) return false;
     *grid = 2 * ceil_div(s.B, LP_BM) * (s.Gp / LP_BN);
     return persist_fits((const void*)k_lstm_fwd_persist, lstm_persist_lds_bytes(s.Hp), *grid);
+}
+// half-width workgroups, two per CU (SAD_LSTM_FWD2=0 keeps the full-width kernel: A/B switch)
+bool lstm_persist2_fits(const Shape& s, int* grid) {
+    static const bool on = getenv("SAD_LSTM_FWD2") == nullptr || atoi(getenv("SAD_LSTM_FWD2")) != 0;
+    if (!on || s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
+    if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
+    *grid = 2 * ceil_div(s.B, LF_BM) * (s.Gp / LF_BN);
+    return persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256);
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
@@ -525,7 +534,10 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
     int pgrid = 0;
     unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
     (void)hipMemsetAsync(sync, 0, wl.bytes[SAD_WS_SYNC], st);   // counters + timeout word, every call
-    if (lstm_persist_fits(s, &pgrid)) {
+    if (lstm_persist2_fits(s, &pgrid)) {
+        hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), st, s, lens,
+                           at<bf16raw>(packed, pl.whh), G, Cs, Hs, at<bf16raw>(ws, wl.off[SAD_WS_HX]), sync);
+    } else if (lstm_persist_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_fwd_persist, dim3(pgrid), dim3(512), lstm_persist_lds_bytes(s.Hp), st, s, lens,
                            at<bf16raw>(packed, pl.whh), G, Cs, Hs, sync);
     } else {

@@ -74,8 +74,15 @@ __device__ __forceinline__ u32x4 pack_bf16x8(f32x4 a, f32x4 b) {
 __device__ __forceinline__ float bf16_to_f32(bf16raw x) { return __builtin_bit_cast(float, (unsigned)x << 16); }
 __device__ __forceinline__ bf16raw f32_to_bf16(float f) { return __builtin_bit_cast(bf16raw, (__bf16)f); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE division expands to ~10 instructions, and the cell update of
+// the recurrence evaluates 5 of these per hidden unit on the critical path of every time step.
+// exp2 overflow -> inf -> rcp -> 0 and underflow -> 0 give the right limits.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -305,6 +305,20 @@ __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
     return (size_t)2 * 2 * ((B + LF_BM - 1) / LF_BM * LF_BM) * Hp * 2;
 }
 
+#ifdef SAD_LF_PROF
+// debug build only: phase timers (100 MHz wall clock) of one workgroup -> the free words after the timeout words
+#define LF_PROF_DECL unsigned long long pt[7] = {0,0,0,0,0,0,0}, pa[7] = {0,0,0,0,0,0,0}; unsigned psteps = 0;
+#define LF_PROF_T(i) pt[i] = wall_clock64();
+#define LF_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0][0]), "v"(acc[1][3][0])); }
+#define LF_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; }
+#define LF_PROF_OUT if (tid == 0 && group == SAD_LF_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)groups * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; }
+#else
+#define LF_PROF_DECL
+#define LF_PROF_T(i)
+#define LF_PROF_ACC
+#define LF_PROF_END
+#define LF_PROF_OUT
+#endif
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int* __restrict__ lens,
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
@@ -361,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     const int nks = Hp / 32;
     unsigned done = 0;
     bool dead = false;
+    LF_PROF_DECL
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
@@ -384,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        LF_PROF_T(0)
         if (done > 0) {
             if (tid == 0 && !dead) {
                 const unsigned target = done * (unsigned)ctiles;
@@ -397,8 +413,10 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                     }
                 }
             }
+            LF_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
             __syncthreads();
+            LF_PROF_T(2)
             // ---- h_{tp} of this wave's 32 sentences: LF_NS sets of 4 k-steps (4 KB per wave each) in flight,
             //      16-byte sc1 loads straight into MFMA fragment registers; gates += h_{tp} . W_hh^T
             const __amdgpu_buffer_rsrc_t rs = lp_rsrc(HX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
@@ -450,6 +468,8 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                 });
             }
         }
+        LF_PROF_ACC
+        LF_PROF_T(3)
         // ---- cell update; publish h_t first, the private stores (Hs, gates, c) after the signal -------
         f32x4 gi[2], gf[2], gg[2], go[2];
         u32x2 hp[2];
@@ -479,7 +499,9 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         const int tmq = q & 1;
         const bool actq = tmq ? act[1] : act[0];
         if (actq) lp_store16_sc1(HX + (done & 1) * xpar + (tmq ? xrow[1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u, hv);
+        LF_PROF_T(4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
+        LF_PROF_T(5)
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
         ++done;
@@ -497,7 +519,10 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
             *(f32x4*)(g + 48) = go[tm];
             *(f32x4*)&Cs[(((long long)t * B + brow[tm]) * 2 + dir) * Hp + j] = creg[tm];
         }
+        LF_PROF_T(6)
+        LF_PROF_END
     }
+    LF_PROF_OUT
 }
 
 }  // namespace sad

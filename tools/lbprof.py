@@ -1,4 +1,5 @@
-"""Phase timing of the persistent BPTT (debug variant library only: built with -DSAD_LB_PROF=<group>,
+"""Phase timing of the persistent BPTT (-DSAD_LB_PROF=<group>) or forward recurrence (-DSAD_LF_PROF=<group>;
+LB_FWD=1) (debug variant library only,
 loaded through SAD_LIB).  Prints 100 MHz wall-clock ticks (10 ns) per step of one workgroup."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,12 +16,13 @@ S, lengths, ln_dev, mask, labels = bench.make_inputs(w, 1234, dev)
 Sv = S.transpose(0, 1).requires_grad_(True)
 for it in range(3):
     loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
-    loss.mean().backward()
+    if not os.environ.get("LB_FWD"):
+        loss.mean().backward()
     torch.cuda.synchronize()
 ws = Fn._Discriminator.last_workspace
 v = ws.view("SYNC", torch.int64)[-12:-5].cpu().tolist()
 n = max(1, v[6])
-names = ["poll", "barrier", "dZ loads + K loop", "epilogue + store issue", "store drain", "barrier + signal"]
+names = ["poll", "barrier", "operand loads + K loop", "epilogue + store issue", "store drain", "barrier + signal (+ private stores, fwd)"]
 print("steps", v[6], " us/step:")
 for nm, x in zip(names, v[:6]):
     print("  %-26s %7.2f" % (nm, x / n / 100.0))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 112 /* 0.1.1 */
+#define SAD_VERSION 113 /* 0.1.1 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -150,6 +150,8 @@ enum sad_ws_field {
                         tile and direction), then the timeout word (non-zero = a wait timed out) */
     SAD_WS_DZX,      /* bf16 [2][2][B/16][Gp/8][16][8] hand-off image of dZ inside the persistent BPTT */
     SAD_WS_HX,       /* bf16 [2][2][B/16][Hp/8][16][8] hand-off image of h inside the persistent recurrence */
+    SAD_WS_K1TILES,  /* int32: count + list of the 128-row tiles with a needed row (stream-K form of K1) */
+    SAD_WS_K1SLABS,  /* fp32 [256][2][128*320] partial tiles of the stream-K form of K1, accumulator-fragment order */
     SAD_WS_NFIELDS
 };
 

@@ -337,11 +337,11 @@ __global__ __launch_bounds__(768) void k_softemb_fwd_ws(Shape s, const void* __r
 // ------------------------------------------------------------------------------------------------
 #ifdef SAD_K1F_PROF
 // debug build only: phase timers of one workgroup, printed by one lane per role
-#define K1P_DECL long long pt_[4] = {0, 0, 0, 0}, pa_[4] = {0, 0, 0, 0}; int pn_ = 0;
+#define K1P_DECL long long pt_[4] = {0, 0, 0, 0}, pa_[4] = {0, 0, 0, 0}; int pn_ = 0; const long long t_begin_ = wall_clock64();
 #define K1P_T(i) pt_[i] = wall_clock64();
 #define K1P_ACC { for (int i_ = 1; i_ < 4; ++i_) pa_[i_] += pt_[i_] - pt_[i_ - 1]; ++pn_; }
 #define K1P_MFMA { float t_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(t_) : "v"(acc[0][0][0]), "v"(acc[C::TM - 1][C::TN - 1][0])); }
-#define K1P_OUT(what) if (blockIdx.x == SAD_K1F_PROF && lane == 0 && (wave == 0 || wave == 8 || wave == 12)) printf("%s: n=%d  %.3f %.3f %.3f us per k-tile\n", what, pn_, pa_[1] / 100.0 / pn_, pa_[2] / 100.0 / pn_, pa_[3] / 100.0 / pn_);
+#define K1P_OUT(what) if (blockIdx.x == SAD_K1F_PROF && lane == 0 && (wave == 0 || wave == 8 || wave == 12)) printf("%s: n=%d  %.3f %.3f %.3f us per k-tile, role total %.1f us\n", what, pn_, pa_[1] / 100.0 / pn_, pa_[2] / 100.0 / pn_, pa_[3] / 100.0 / pn_, (wall_clock64() - t_begin_) / 100.0);
 #else
 #define K1P_DECL
 #define K1P_T(i)
@@ -540,6 +540,330 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_ws3(Shape s, const void* _
         for (int tn = 0; tn < C::TN; ++tn) {
             const int n = frag_col<C>(wn, tn, lane);
             if (m < M && n < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 as STREAM-K over (row tile, k-tile) units: a ragged batch leaves ~45 % of the 128-row tiles
+// empty, so one workgroup per tile keeps only ~141 of 256 CUs busy, each streaming all of W_emb^T
+// (6 MB) at the per-CU L2 read rate.  Here the non-empty tiles are listed (k_tile_list), the
+// ntiles * nk units are cut into gridDim.x equal contiguous ranges, and a workgroup runs the
+// three-role pipeline of k_softemb_fwd_ws3 over each (tile, k-range) segment of its range.  A segment
+// that covers a whole tile stores bf16 X directly; the (at most two) partial segments of a workgroup
+// go to fp32 slabs in accumulator-fragment order (1 KB per wave store) and k_softemb_fwd_fix adds the
+// slabs of a tile in workgroup order: the result does not depend on timing.
+// ------------------------------------------------------------------------------------------------
+constexpr int K1_SLAB_FLOATS = 128 * 320;                   // one partial tile
+constexpr int K1_MAX_WGS = 256;
+
+// Unit ranges of the workgroups.  Equal ranges of ceil(total / G) units start every workgroup at a
+// different k, so the 32 workgroups of an XCD sweep W_emb^T (6 MB > the 4 MB L2) out of step and nearly
+// every W tile comes from the Infinity Cache (measured: FETCH_SIZE 1.05 GB per launch, 1.9 us per unit).
+// Instead workgroup g takes units [g*a*nk/16, (g+1)*a*nk/16): ranges of a/16 of a tile, so there are
+// only 16 distinct start offsets, and because blocks g, g+8, ... share an XCD (speed only) an XCD
+// hosts two cohorts of 16 workgroups that advance through k in step and share their W tiles in L2.
+__host__ __device__ inline int k1_sixteenths(int ntiles, int G) {           // a: smallest with ceil(16 ntiles / a) <= G
+    const int a = (16 * ntiles + G - 1) / G;
+    return a < 1 ? 1 : a;
+}
+__host__ __device__ inline long long k1_u0(int g, int a, int nk) { return (long long)g * a * nk / 16; }
+// the workgroup whose range holds unit u
+__host__ __device__ inline int k1_wg_of(long long u, int a, int nk) {
+    const long long d = (long long)a * nk;
+    return (int)(((u + 1) * 16 + d - 1) / d) - 1;
+}
+
+// tiles[0] = number of 128-row tiles with a needed row, tiles[1..] = their indices (ascending).
+__global__ __launch_bounds__(1024) void k_tile_list(int M, const unsigned char* __restrict__ need, int* __restrict__ tiles) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = (M + 127) / 128;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < nt; t0 += 1024) {
+        const int ti = t0 + tid;
+        int f = 0;
+        if (ti < nt) {
+            const int m0 = ti * 128, rows = M - m0 < 128 ? M - m0 : 128;
+            if (rows == 128 && ((unsigned long long)(need + m0) & 15) == 0) {
+                u32x4 o = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4 v = *(const u32x4*)(need + m0 + 16 * i);
+                    o[0] |= v[0]; o[1] |= v[1]; o[2] |= v[2]; o[3] |= v[3];
+                }
+                f = (o[0] | o[1] | o[2] | o[3]) != 0;
+            } else {
+                for (int r = 0; r < rows; ++r) f |= need[m0 + r] != 0;
+            }
+        }
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (f) tiles[1 + off + before] = ti;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) tiles[0] = base;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __restrict__ src, long long sT, long long sB,
+                                                       const unsigned char* __restrict__ need, const int* __restrict__ tiles,
+                                                       const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X,
+                                                       float* __restrict__ slabs) {
+    typedef Cfg<128, 320, 2, 4, 1> C;
+    typedef SoftRow<KIND> SR;
+    typedef typename SR::Elem Elem;
+    constexpr int ABYTES = 128 * 128, BBYTES = 320 * 128, BOFF = 2 * ABYTES;   // LDS: A0 A1 B0 B1 B2
+    constexpr int D = sizeof(typename SR::Raw) > 16 ? 2 : SAD_K1F_D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = s.M, V = s.V, Vp = s.Vp;
+    const int nk = (V + 63) / 64, nkf = V / 64;
+    // this workgroup's range of units (every wave computes the same numbers)
+    const int total = tiles[0] * nk;
+    const int sx = k1_sixteenths(tiles[0], (int)gridDim.x);
+    const long long u0l = k1_u0((int)blockIdx.x, sx, nk), u1l = k1_u0((int)blockIdx.x + 1, sx, nk);
+    if (u0l >= total) return;
+    const int u0 = (int)u0l, u1 = u1l < total ? (int)u1l : total;
+    if (u0 >= u1) return;
+    const int first_tile = u0 / nk;
+
+    K1P_DECL
+    if (wave >= 12) {
+        // ---------------------------------- W loader waves -------------------------------------
+        for (int u = u0; u < u1;) {
+        const int ti = u / nk, ka = u - ti * nk;
+        const int kb = ka + (u1 - u) < nk ? ka + (u1 - u) : nk;
+        const int n = kb - ka;                                 // k-tiles of this segment, >= 1
+        u += n;
+            const int ww = wave - 12, r = lane >> 3, sl = lane & 7;
+            const bf16raw* be = wembT + (long long)(ww * 80 + r) * Vp + ((sl ^ (r >> 1)) << 3) + ka * 64;
+            const bf16raw* bo = wembT + (long long)(ww * 80 + 8 + r) * Vp + ((sl ^ (4 + (r >> 1))) << 3) + ka * 64;
+            const long long step2 = 16ll * Vp;
+            auto issue = [&](int j, int st) {
+                unsigned char* dst = fw_lds + BOFF + st * BBYTES + ww * (80 * 128);
+                const int k0 = j * 64;
+#pragma unroll
+                for (int y = 0; y < 5; ++y) {
+                    __builtin_amdgcn_global_load_lds((gmem_cv*)(be + y * step2 + k0), (lds_v*)(dst + (2 * y) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gmem_cv*)(bo + y * step2 + k0), (lds_v*)(dst + (2 * y + 1) * 1024), 16, 0, 0);
+                }
+            };
+            issue(0, 0);
+            if (n > 1) {
+                issue(1, 1);
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                      // k-tile 0 of the segment ready
+            int st2 = 2;
+            for (int j = 0; j < n; ++j) {
+                K1P_T(0)
+                if (j + 2 < n) {
+                    issue(j + 2, st2);
+                    K1P_T(1)
+                    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                } else {
+                    K1P_T(1)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                K1P_T(2)
+                st2 = st2 == 2 ? 0 : st2 + 1;
+                __builtin_amdgcn_s_barrier();
+                K1P_T(3)
+                K1P_ACC
+            }
+        }
+        K1P_OUT("W loader: issue, wait, barrier")
+        return;
+    }
+    if (wave >= 8) {
+        // ---------------------------------- S loader waves -------------------------------------
+        for (int u = u0; u < u1;) {
+        const int ti = u / nk, ka = u - ti * nk;
+        const int kb = ka + (u1 - u) < nk ? ka + (u1 - u) : nk;
+        const int n = kb - ka;                                 // k-tiles of this segment, >= 1
+        const int m0 = tiles[1 + ti] * 128;
+        u += n;
+            const int lt = tid - 512;                          // 0..255: tile row lt/8 + 32 i, 16-byte chunk lt%8
+            const int r0 = lt >> 3, c0 = lt & 7;
+            const Elem* arow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + r0 + 32 * i;
+                arow[i] = nullptr;
+                if (m < M && need[m]) {
+                    const int t = m / s.B, b = m - t * s.B;
+                    arow[i] = (const Elem*)src + (long long)t * sT + (long long)b * sB + c0 * 8;
+                }
+            }
+            const int aoff0 = lds_off<C>(r0, c0) * 2;          // row + 32 i keeps the swizzle: + i * 4096 bytes
+            typename SR::Raw ra[D][4];
+            const Elem* dummy = (const Elem*)src;
+            // whole k-tiles of this segment: relative j < nw (absolute ka + j < nkf); loads are clamped to them
+            const int nw = (nkf < kb ? nkf : kb) - ka;         // may be <= 0: the segment is the ragged tile alone
+            auto load_tile = [&](auto par, int j) {
+                constexpr int P = decltype(par)::value;
+                const int k0 = (ka + (j < nw ? j : nw - 1)) * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_fast(arow[i], dummy, k0);
+            };
+            auto to_lds = [&](auto par, int j) {
+                constexpr int P = decltype(par)::value;
+                unsigned char* buf = fw_lds + (j & 1) * ABYTES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(u32x4*)&buf[aoff0 + i * 4096] = typename SR::Cvt()(ra[P][i]);
+            };
+            auto tail_to_lds = [&](int j) {                    // the ragged last k-tile: element-guarded loads
+                unsigned char* buf = fw_lds + (j & 1) * ABYTES;
+                const int k0 = (ka + j) * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(u32x4*)&buf[aoff0 + i * 4096] =
+                        typename SR::Cvt()(SR::load(arow[i] != nullptr ? arow[i] - c0 * 8 : nullptr, k0 + c0 * 8, V));
+            };
+            int j = 0;
+            if (nw >= 1) {
+                static_for<D>([&](auto d) { load_tile(d, decltype(d)::value); });
+                to_lds(std::integral_constant<int, 0>{}, 0);
+                load_tile(std::integral_constant<int, 0>{}, D);
+            } else {
+                tail_to_lds(0);
+            }
+            __syncthreads();                                   // k-tile 0 of the segment ready
+            for (; j + D < nw; j += D) {                       // steady state, branch-free
+                static_for<D>([&](auto uu) {
+                    constexpr int U = decltype(uu)::value;
+                    using P = std::integral_constant<int, (U + 1) % D>;
+                    K1P_T(0)
+                    to_lds(P{}, j + U + 1);
+                    K1P_T(1)
+                    load_tile(P{}, j + U + 1 + D);
+                    K1P_T(2)
+                    __syncthreads();
+                    K1P_T(3)
+                    K1P_ACC
+                });
+            }
+            for (; j < n; ++j) {
+                if (j + 1 < nw) {
+                    static_for<D>([&](auto d) {
+                        if ((j + 1) % D == decltype(d)::value) to_lds(d, j + 1);
+                    });
+                } else if (j + 1 < n) {
+                    tail_to_lds(j + 1);
+                }
+                __syncthreads();
+            }
+        }
+        K1P_OUT("S loader: to_lds (wait + write), issue, barrier")
+        return;
+    }
+    // -------------------------------------- compute waves ------------------------------------
+    for (int u = u0; u < u1;) {
+        const int ti = u / nk, ka = u - ti * nk;
+        const int kb = ka + (u1 - u) < nk ? ka + (u1 - u) : nk;
+        const int n = kb - ka;                                 // k-tiles of this segment, >= 1
+        const int m0 = tiles[1 + ti] * 128;
+        u += n;
+        const int wm = wave / C::WN, wn = wave % C::WN;
+        f32x4 acc[C::TM][C::TN];
+        zero_acc<C>(acc);
+        __syncthreads();                                       // k-tile 0 of the segment ready
+        int st = 0;
+        for (int j = 0; j < n; ++j) {
+            K1P_T(0)
+            K1P_T(1)
+            const bf16raw* As = (const bf16raw*)(fw_lds + (j & 1) * ABYTES);
+            const bf16raw* Bs = (const bf16raw*)(fw_lds + BOFF + st * BBYTES);
+            st = st == 2 ? 0 : st + 1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[C::TM], bfr[C::TN];
+                const int ch = kk * 4 + (lane >> 4);
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm) af[tm] = *(const bf16x8*)&As[lds_off<C>(frag_row<C>(wm, tm, lane), ch)];
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn)
+                    bfr[tn] = *(const bf16x8*)&Bs[lds_off<C>(wn * (C::BN / C::WN) + tn * 16 + (lane & 15), ch)];
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
+            }
+            K1P_MFMA
+            K1P_T(2)
+            __syncthreads();                                   // k-tile consumed; the next one written by the loaders
+            K1P_T(3)
+            K1P_ACC
+        }
+        if (n == nk) {
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+                const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    const int nn = frag_col<C>(wn, tn, lane);
+                    if (m < M && nn < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + nn] = pack_bf16x4(acc[tm][tn]);
+                }
+            }
+        } else {
+            const int slot = ti == first_tile ? 0 : 1;
+            float* slab = slabs + ((long long)blockIdx.x * 2 + slot) * K1_SLAB_FLOATS + (long long)wave * (C::TM * C::TN * 256);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) *(f32x4*)&slab[((tm * C::TN + tn) * 64 + lane) * 4] = acc[tm][tn];
+        }
+    }
+    K1P_OUT("compute: -, reads + MFMA, barrier")
+}
+
+// Adds the slabs of every row tile that k_softemb_fwd_sk split over workgroups (in workgroup order) and
+// writes its bf16 X rows.  Same unit partition (nwg = the stream-K grid).  One wave per block:
+// block (ti, w) takes the accumulator fragments of compute wave w, all loads of a slab in flight.
+__global__ __launch_bounds__(64) void k_softemb_fwd_fix(Shape s, const int* __restrict__ tiles, int nwg,
+                                                       const float* __restrict__ slabs, bf16raw* __restrict__ X) {
+    typedef Cfg<128, 320, 2, 4, 1> C;
+    const int ti = blockIdx.x;
+    if (ti >= tiles[0]) return;
+    const int nk = (s.V + 63) / 64;
+    const int sx = k1_sixteenths(tiles[0], nwg);
+    const int g0 = k1_wg_of((long long)ti * nk, sx, nk), g1 = k1_wg_of((long long)(ti + 1) * nk - 1, sx, nk);
+    if (g0 == g1) return;                                      // one workgroup had the whole tile: stored directly
+    const int lane = threadIdx.x, wave = blockIdx.y;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int m0 = tiles[1 + ti] * 128;
+    f32x4 v[C::TM * C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM * C::TN; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = g0; g <= g1; ++g) {
+        const int slot = (int)(k1_u0(g, sx, nk) / nk) == ti ? 0 : 1;
+        const float* slab = slabs + ((long long)g * 2 + slot) * K1_SLAB_FLOATS + (long long)wave * (C::TM * C::TN * 256);
+#pragma unroll
+        for (int i = 0; i < C::TM * C::TN; ++i) v[i] += *(const f32x4*)&slab[(i * 64 + lane) * 4];
+    }
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int nn = frag_col<C>(wn, tn, lane);
+            if (m < s.M && nn < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + nn] = pack_bf16x4(v[tm * C::TN + tn]);
         }
     }
 }

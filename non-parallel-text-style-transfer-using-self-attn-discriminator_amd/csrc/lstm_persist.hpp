@@ -381,24 +381,21 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         const int t = dir ? T - 1 - step : step;
         if (!(maxlen > t)) continue;                         // group-uniform: no sentence of the tile is alive
         const int tp = dir ? t + 1 : t - 1;
-        f32x4 pre[2][4];
+        // accumulators start from the gate pre-activations of this step (private to the workgroup,
+        // independent of h: issued before the wait)
+        f32x4 acc[2][4];
         bool act[2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
             act[tm] = blen[tm] > t;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) acc[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (act[tm]) {
                 const float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) pre[tm][gq] = *(const f32x4*)(g + 16 * gq);
+                for (int gq = 0; gq < 4; ++gq) acc[tm][gq] = *(const f32x4*)(g + 16 * gq);
             }
         }
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
         LF_PROF_T(0)
         if (done > 0) {
             if (tid == 0 && !dead) {
@@ -477,8 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         for (int tm = 0; tm < 2; ++tm) {
             hp[tm] = u32x2{0u, 0u};
             if (!act[tm]) continue;
-            const f32x4 pi = acc[tm][0] + pre[tm][0], pf = acc[tm][1] + pre[tm][1];
-            const f32x4 pg = acc[tm][2] + pre[tm][2], po = acc[tm][3] + pre[tm][3];
+            const f32x4 pi = acc[tm][0], pf = acc[tm][1], pg = acc[tm][2], po = acc[tm][3];
             const f32x4 cprev = creg[tm];     // still zero at a sentence's first step in this direction
             f32x4 c, h;
 #pragma unroll

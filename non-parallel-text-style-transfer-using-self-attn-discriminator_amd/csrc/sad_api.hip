@@ -95,6 +95,9 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
     w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
     w.bytes[SAD_WS_HX] = lstm_fwd_xchg_bytes(s.B, s.Hp);
+    const bool k1_sk = s.Ep == 320 && s.M > 16384;          // the stream-K form of K1 (run_softemb_fwd)
+    w.bytes[SAD_WS_K1TILES] = k1_sk ? ((size_t)ceil_div(s.M, 128) + 4) * 4 : 0;
+    w.bytes[SAD_WS_K1SLABS] = k1_sk ? (size_t)K1_MAX_WGS * 2 * K1_SLAB_FLOATS * 4 : 0;
     size_t o = 0;
     for (int i = 0; i < SAD_WS_NFIELDS; ++i) {
         w.off[i] = o;
@@ -184,7 +187,7 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const bool wide = s.Ep > 128;
     const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles (measured: B=64 166 -> 93 us, B=1024 302 -> 417 us)
     static const bool fwd_ws = getenv("SAD_K1F_WS") == nullptr || atoi(getenv("SAD_K1F_WS")) != 0;   // A/B switch
-    static const int fwd_ws_kind = getenv("SAD_K1F_WS") == nullptr ? 3 : atoi(getenv("SAD_K1F_WS"));
+    static const int fwd_ws_kind = getenv("SAD_K1F_WS") == nullptr ? 4 : atoi(getenv("SAD_K1F_WS"));
     if (fwd_ws && s.Ep == 320 && !small_m && (kind == SAD_SRC_F32 || kind == SAD_SRC_BF16)) {
         if (check_aligned(src, kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
         const dim3 grid(ceil_div(s.M, 128));
@@ -195,7 +198,25 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
         hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), LDS, st, s, src, sT, sB, need, wembT, X);                    \
     }
         constexpr size_t lds2 = 2 * (128 * 128 + 320 * 128), lds3 = 2 * 128 * 128 + 3 * 320 * 128;
-        if (fwd_ws_kind == 3) {     // S and W loader waves apart (deep S prefetch, LDS-direct W)
+        if (fwd_ws_kind >= 4) {     // stream-K over the non-empty row tiles: every CU gets an equal share
+            int* tiles = at<int>(ws, wl.off[SAD_WS_K1TILES]);
+            float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
+            int dev = 0, cus = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const int nwg = cus < 1 ? 1 : (cus > K1_MAX_WGS ? K1_MAX_WGS : cus);
+            hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
+#define SAD_K1SK_LAUNCH(KERNEL)                                                                                   \
+    {                                                                                                             \
+        static const hipError_t e_ = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, lds3); \
+        (void)e_;                                                                                                 \
+        hipLaunchKernelGGL(KERNEL, dim3(nwg), dim3(1024), lds3, st, s, src, sT, sB, need, tiles, wembT, X, slabs); \
+    }
+            if (kind == SAD_SRC_F32) SAD_K1SK_LAUNCH(k_softemb_fwd_sk<SRC_F32>)
+            else SAD_K1SK_LAUNCH(k_softemb_fwd_sk<SRC_BF16>)
+#undef SAD_K1SK_LAUNCH
+            hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8), dim3(64), 0, st, s, tiles, nwg, slabs, X);
+        } else if (fwd_ws_kind == 3) {     // S and W loader waves apart (deep S prefetch, LDS-direct W)
             if (kind == SAD_SRC_F32) SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_F32>, lds3, 1024)
             else SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_BF16>, lds3, 1024)
         } else {

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SAD_LIB") or os.path.join(_HERE, "_native", "libsad.s
 SRC_IDS, SRC_F32, SRC_BF16 = 0, 1, 2
 
 WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", "DX", "DU", "DQ",
-             "DHFIN", "DC", "ACCF", "DL", "DWA", "DSSUM", "ROWS", "NROWS", "SYNC", "DZX", "HX")
+             "DHFIN", "DC", "ACCF", "DL", "DWA", "DSSUM", "ROWS", "NROWS", "SYNC", "DZX", "HX", "K1TILES", "K1SLABS")
 
 # every symbol include/sad.h declares (tests/test_cabi.py checks the .so exports all of them)
 EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",

@@ -526,6 +526,35 @@ def test_long_sequences_vs_oracle():
     assert max(errs.values()) < BF16_TOL_BWD, errs
 
 
+def test_large_batch_dense_soft_tokens_vs_oracle():
+    """M = B*T above the small-batch switch with DENSE soft tokens, ragged sorted lengths and a vocabulary
+    that is not a multiple of the k-tile (the stream-K form of K1: partial tiles of several workgroups
+    are added up by the fix-up kernel; three-role pipeline with LDS-direct W loads; ragged last k-tile;
+    two-workgroups-per-CU recurrence).  Checked: the embedded tokens X of every needed row against
+    S . W_emb in fp64, and forward / dS of 16 sentences against the oracle run on just those."""
+    B, T, V, E, H = 640, 30, 1111, 300, 512
+    lengths = np.sort(synth.make_lengths(B, T, seed=9))[::-1].copy()
+    params = synth.make_params(V, E, H, seed=4)
+    S = bf16_round(synth.make_soft_tokens(B, T, V, lengths, seed=3, kind="dense", time_major=False))
+    labels = synth.make_labels(B, seed=2)
+    mask = synth.transfer_mask(lengths, T)
+    for s_dtype in ("bf16", "f32"):
+        out = run_sad(params, S, lengths, mask, labels, s_dtype=s_dtype, want_ws=True)
+        X = out["ws"]["X"][:, :, :E]                                     # [T,B,E]
+        Wb = bf16_round(params["embedding.weight"]).astype(np.float64)
+        ref = np.einsum("btv,ve->tbe", S.astype(np.float64), Wb)
+        alive = (np.arange(T)[:, None] < lengths[None, :])
+        errX = np.abs(X - ref)[alive].max() / np.abs(ref[alive]).max()
+        sel = np.linspace(0, B - 1, 16).astype(int)
+        f, b = _oracle(params, S[sel], lengths[sel], mask[sel], labels[sel], dloss=np.full((16,), 1.0 / B))
+        errs = dict(X=errX, logits=relerr(out["logits"][sel], f["logits"]), weights=relerr(out["weights"][sel], f["weights"]),
+                    loss=relerr(out["loss"][sel], f["loss"]), dS=relerr(out["dS"][sel], b["dS"]))
+        _report("large batch dense soft tokens (%s)" % s_dtype, errs)
+        assert errX < 6e-3, errX                                         # bf16 storage of X: half an ulp = 2^-9
+        assert errs["logits"] < BF16_TOL_FWD and errs["weights"] < BF16_TOL_FWD and errs["loss"] < BF16_TOL_FWD
+        assert errs["dS"] < BF16_TOL_BWD * 1.5
+
+
 def test_ragged_and_edge_shapes():
     """Edge cases: B=1, all lengths equal to T, len==2 rows (all-masked guard), a batch and T that
     are not multiples of any tile size, unsorted lengths given on the device (no host check)."""

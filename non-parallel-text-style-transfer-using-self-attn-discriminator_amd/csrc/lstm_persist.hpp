@@ -539,7 +539,7 @@ namespace sad {
 // Hand-off protocol: as in k_lstm_fwd_persist.
 // ------------------------------------------------------------------------------------------------
 #ifndef SAD_LB_NS
-#define SAD_LB_NS 3
+#define SAD_LB_NS 2
 #endif
 constexpr int LB_BM = 128, LB_BN = 32, LB_SG_MAX = 16, LB_NS = SAD_LB_NS;       // Gp <= 128 * LB_SG_MAX
 

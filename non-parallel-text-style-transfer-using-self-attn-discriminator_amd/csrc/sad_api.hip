@@ -681,6 +681,38 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     {
         float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
         const bool wide = s.Ep > 128;
+        // Large batches at Ep = 320: the same GEMM shape as K1 (A = dZ rows, B = Wcat^T, K = Ncat), so it
+        // runs on K1's pipelined kernels with a patched shape: 3 = three wave roles, 4 = + stream-K
+        // (SAD_INPROJ_BWD_WS=0: the single-role kernel; A/B switch).
+        static const int ws_kind = getenv("SAD_INPROJ_BWD_WS") == nullptr ? 3 : atoi(getenv("SAD_INPROJ_BWD_WS"));
+        if (ws_kind >= 3 && s.Ep == 320 && s.M > 16384 && s.Ncat % 64 == 0 && wl.bytes[SAD_WS_K1SLABS] != 0) {
+            Shape sp = s;
+            sp.V = s.Ncat;
+            sp.Vp = s.Ncat;
+            constexpr size_t lds3 = 2 * 128 * 128 + 3 * 320 * 128;
+            const bf16raw* wT = at<bf16raw>(packed, pl.wcatT);
+            if (ws_kind >= 4) {
+                int* tiles = at<int>(ws, wl.off[SAD_WS_K1TILES]);
+                float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
+                int dev = 0, cus = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                const int nwg = cus < 1 ? 1 : (cus > K1_MAX_WGS ? K1_MAX_WGS : cus);
+                hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
+                static const hipError_t e_ = hipFuncSetAttribute((const void*)k_softemb_fwd_sk<SRC_BF16>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                (void)e_;
+                hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_BF16>, dim3(nwg), dim3(1024), lds3, st, sp, (const void*)DZ,
+                                   (long long)s.B * s.Ncat, (long long)s.Ncat, need, tiles, wT, DX, slabs);
+                hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8), dim3(64), 0, st, sp, tiles, nwg, slabs, DX);
+            } else {
+                static const hipError_t e_ = hipFuncSetAttribute((const void*)k_softemb_fwd_ws3<SRC_BF16>,
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                (void)e_;
+                hipLaunchKernelGGL(k_softemb_fwd_ws3<SRC_BF16>, dim3(ceil_div(s.M, 128)), dim3(1024), lds3, st, sp,
+                                   (const void*)DZ, (long long)s.B * s.Ncat, (long long)s.Ncat, need, wT, DX);
+            }
+        } else {
         const int bm = 128, bn = wide ? 320 : 64;
         const int ksplit = split_k(ceil_div(s.M, bm) * ceil_div(s.Ep, bn), ceil_div(s.Ncat, 64));
         dim3 grid(ceil_div(s.M, bm), ceil_div(s.Ep, bn), ksplit);
@@ -692,6 +724,7 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
             hipLaunchKernelGGL((k_inproj_bwd<CfgNarrowN>), grid, dim3(CfgNarrowN::NT), 0, st, s, DZ, need,
                                at<bf16raw>(packed, pl.wcatT), DX, accf, ksplit);
         if (ksplit > 1) launch_cvt(accf, DX, (long long)s.M * s.Ep, st);
+        }
     }
     SAD_CHECK_LAUNCH("k_inproj_bwd");
     if (a->drop_keep != nullptr) {      // d(embedded tokens) in front of the dropout

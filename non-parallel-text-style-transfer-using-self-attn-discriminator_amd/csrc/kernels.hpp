@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(C::NT) void k_softemb_bwd(Shape s, const bf16raw* _
 //     also covers the stores of tile nt-1, which by then had a whole MFMA phase to drain.
 // PAIR: epi(tm, n, lo, hi) = columns [n, n+8) of this lane's row tm; else epi(tm, n, v) = [n, n+4).
 // ------------------------------------------------------------------------------------------------
-template <int KS, bool PAIR, class Epi>
+template <int KS, int PAIR, class Epi>     // PAIR: 0 = epi per accumulator tile, 1 = per pair of tiles, 2 = per 64-column tile (all of acc)
 __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, const int (&mrow)[2], bool wave_any,
                                         int block_any, const bf16raw* __restrict__ Bt, int nt0, int nt1,
                                         unsigned char* Bs, Epi epi) {
@@ -1591,7 +1591,7 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
         const int g = tid + i * NTH;
         const int vloc = g / CPR, ch = g - vloc * CPR;
         // PAIR: vloc = 32p + 8g + 4tau + r  <->  rho = 32p + 16tau + 4g + r ; else identity
-        const int rho = PAIR ? (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3) : vloc;
+        const int rho = PAIR == 1 ? (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3) : vloc;
         soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
         goff[i] = g * 8;                    // elements from the tile's first row (tile is contiguous)
     }
@@ -1646,15 +1646,16 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
         }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
-            if constexpr (PAIR) {
+            if constexpr (PAIR == 1) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
                     epi(tm, nt * BN + 32 * pr + 8 * (lane >> 4), acc[tm][2 * pr], acc[tm][2 * pr + 1]);
-            } else {
+            } else if constexpr (PAIR == 0) {
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) epi(tm, nt * BN + 16 * tn + 4 * (lane >> 4), acc[tm][tn]);
             }
         }
+        if constexpr (PAIR == 2) epi(nt, acc);
         if (block_any && nt + 2 < nt1) load_tile(nt + 2);
     }
 }
@@ -1744,7 +1745,7 @@ __device__ __forceinline__ void rs_gemm_ws(const bf16raw* __restrict__ A, int M,
         for (int i = 0; i < SCH; ++i) {
             const int g = lt + i * NLOAD;
             const int vloc = g / CPR, ch = g - vloc * CPR;
-            const int rho = PAIR ? (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3) : vloc;
+            const int rho = PAIR == 1 ? (vloc & 32) + 16 * ((vloc >> 2) & 1) + 4 * ((vloc >> 3) & 3) + (vloc & 3) : vloc;
             soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
             goff[i] = g * 8;
         }
@@ -2092,6 +2093,237 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs(Shape s, const bf16raw* _
         float* p = n < G2 ? G + (long long)mrow[tm] * s.Gld + n : Kk + (long long)mrow[tm] * s.Hp + (n - G2);
         *(f32x4*)p = v;
     });
+}
+
+// K2a + K3, A-stationary, with the output tile turned through a wave-private LDS scratch: the
+// accumulator layout gives 16-byte pieces of 16 different rows per quarter wave; after the turn a
+// store instruction writes full 128-byte row segments of 8 rows.  No extra workgroup barrier: a
+// wave's LDS operations execute in program order.
+template <int KS>
+__global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* __restrict__ X,
+                                                       const unsigned char* __restrict__ need,
+                                                       const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
+                                                       float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
+    unsigned char* Bs = ip_lds;                                          // 64 * KS * 64 bytes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* scr = ip_lds + 64 * KS * 64 + wave * 8192;            // [32 rows][64 cols] fp32, 256-byte rows
+    const int m0 = blockIdx.x * 256;
+    const int ntiles = s.Ncat / 64;
+    const int nt0 = blockIdx.y * nt_per;
+    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
+    const int M = s.M, G2 = 2 * s.Gp;
+    int mrow[2];
+    int rneed = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = m0 + wave * 32 + tm * 16 + (lane & 15);
+        mrow[tm] = m;
+        rneed |= (m < M && need[m] != 0) ? 1 : 0;
+    }
+    const bool wave_any = __any(rneed != 0);
+    const int block_any = __syncthreads_or(rneed != 0);
+    if (!block_any) return;
+    // store side: lane -> rows (lane >> 4) + 4 i of the wave's 32, 16-byte chunk lane & 15 of the 256-byte row
+    int srow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wave * 32 + (lane >> 4) + 4 * i;
+        srow[i] = (m < M && need[m] != 0) ? m : -1;
+    }
+    const int sc = lane & 15;
+    rs_gemm<KS, 2>(X, M, mrow, wave_any, block_any, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
+        if (!wave_any) return;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int r = tm * 16 + (lane & 15);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const int c = tn * 4 + (lane >> 4);
+                *(f32x4*)&scr[r * 256 + ((c ^ (r & 15)) << 4)] = acc[tm][tn];
+            }
+        }
+        const int n = nt * 64 + sc * 4;
+        const f32x4 bias = *(const f32x4*)&bcat[n];
+        float* base = n < G2 ? G + n : Kk + (n - G2);
+        const long long ld = n < G2 ? s.Gld : s.Hp;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (lane >> 4) + 4 * i;
+            const f32x4 v = *(const f32x4*)&scr[r * 256 + ((sc ^ (r & 15)) << 4)];
+#ifndef SAD_NO_NT_G
+            // written once, read once by the recurrence much later: keep it out of the L2's way
+            if (srow[i] >= 0) __builtin_nontemporal_store(v + bias, (f32x4*)(base + (long long)srow[i] * ld));
+#else
+            if (srow[i] >= 0) *(f32x4*)(base + (long long)srow[i] * ld) = v + bias;
+#endif
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a + K3 with LOADER, COMPUTE and STORE waves (768 threads, Ep == 32*KS, Ncat % 32 == 0).
+// The kernel is bound by its fp32 output (rows x Ncat x 4 bytes); the accumulator layout only gives
+// 16-byte pieces of 16 different rows per quarter wave, which the memory pipe takes at a fraction of
+// its rate.  Same treatment as K1' (k_softemb_bwd_ws2):
+//   waves 0-7   compute: X fragments of 256 rows in registers, 40 MFMAs per 32-column tile, results
+//               -> LDS output tile [256][32] fp32;
+//   waves 8-9   loaders: Wcat tile nt+1 (20 KB, contiguous) -> LDS while tile nt is multiplied;
+//   waves 10-11 storers: tile nt-1 from LDS (+ bias) -> G / Kk as full 128-byte row segments, 8 rows per
+//               instruction.  Rows nobody reads (need == 0) are not written.
+// LDS: 2 x 20 KB Wcat tiles + 2 x 32 KB output tiles, one workgroup barrier per tile.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(768) void k_inproj_fwd_ws2(Shape s, const bf16raw* __restrict__ X,
+                                                       const unsigned char* __restrict__ need,
+                                                       const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
+                                                       float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
+    constexpr int EP = KS * 32, BN = 32;
+    constexpr int ROWB = EP * 2, CPR = EP / 8, TILEB = BN * ROWB;
+    constexpr int NLOAD = 128, SCH = BN * CPR / NLOAD;        // loader threads, chunks per thread and tile
+    constexpr int OUTB = 256 * BN * 4;                        // one output tile: [256][32] fp32, 128-byte rows
+    static_assert((BN * CPR) % NLOAD == 0, "tile must split evenly over the loader waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
+    unsigned char* Bs = ip_lds;                                // 2 x TILEB
+    unsigned char* Os = ip_lds + 2 * TILEB;                    // 2 x OUTB, chunk c of row r at r*128 + ((c ^ (r&7)) << 4)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 256;
+    const int ntiles = s.Ncat / BN;
+    const int nt0 = blockIdx.y * nt_per;
+    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
+    const int ntl = nt1 - nt0;
+    const int M = s.M, G2 = 2 * s.Gp;
+    {   // row blocks nobody reads are skipped (every wave takes the same decision)
+        int any = 0;
+        for (int r = tid; r < 256; r += 768)
+            if (m0 + r < M && need[m0 + r]) any = 1;
+        if (!__syncthreads_or(any) || ntl <= 0) return;
+    }
+
+    if (wave >= 10) {
+        // -------------------------------------- store waves --------------------------------------
+        const int ls = tid - 640, c = ls & 7;
+        int mrow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + (ls >> 3) + 16 * i;
+            mrow[i] = (m < M && need[m]) ? m : -1;
+        }
+        __syncthreads();                                       // prologue barrier
+        for (int it = 0; it <= ntl; ++it) {
+            if (it >= 1) {
+                const unsigned char* buf = Os + ((it - 1) & 1) * OUTB;
+                const int n = (nt0 + it - 1) * BN + c * 4;
+                const f32x4 bias = *(const f32x4*)&bcat[n];
+                float* base = n < G2 ? G + n : Kk + (n - G2);
+                const long long ld = n < G2 ? s.Gld : s.Hp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (ls >> 3) + 16 * i;
+                    const f32x4 v = *(const f32x4*)&buf[r * 128 + ((c ^ (r & 7)) << 4)];
+                    if (mrow[i] >= 0) *(f32x4*)(base + (long long)mrow[i] * ld) = v + bias;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    if (wave >= 8) {
+        // -------------------------------------- loader waves -------------------------------------
+        const int lt = tid - 512;
+        int soff[SCH], goff[SCH];
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) {
+            const int g = lt + i * NLOAD;
+            const int rho = g / CPR, ch = g - rho * CPR;
+            soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
+            goff[i] = g * 8;
+        }
+        u32x4 st[SCH];
+        auto load_tile = [&](int k) {                          // clamped, never skipped
+            const bf16raw* base = wcat + (long long)(nt0 + (k < ntl ? k : ntl - 1)) * BN * EP;
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
+        };
+        auto to_lds = [&](int k) {
+            unsigned char* buf = Bs + (k & 1) * TILEB;
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) *(u32x4*)&buf[soff[i]] = st[i];
+        };
+        load_tile(0);
+        to_lds(0);
+        load_tile(1);
+        __syncthreads();                                       // prologue barrier: tile 0 ready
+        for (int it = 0; it <= ntl; ++it) {
+            if (it + 1 < ntl) {
+                to_lds(it + 1);
+                load_tile(it + 2);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------------------------------- compute waves --------------------------------------
+    int mrow[2];
+    int rneed = 0;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        mrow[tm] = m0 + wave * 32 + tm * 16 + (lane & 15);
+        if (mrow[tm] < M) rneed |= need[mrow[tm]];
+    }
+    const bool wave_any = __any(rneed != 0);
+    bf16x8 a[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(X + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
+            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    int roff[2], rsw[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int rho = tn * 16 + (lane & 15);
+        roff[tn] = rho * ROWB;
+        rsw[tn] = (rho >> 1) & 7;
+    }
+    __syncthreads();                                           // prologue barrier
+    for (int it = 0; it <= ntl; ++it) {
+        if (it < ntl) {
+            const unsigned char* buf = Bs + (it & 1) * TILEB;
+            unsigned char* ob = Os + (it & 1) * OUTB;
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wave_any) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 bfr[2];
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        bfr[tn] = *(const bf16x8*)&buf[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int r = wave * 32 + tm * 16 + (lane & 15);
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int c = tn * 4 + (lane >> 4);        // columns 16 tn + 4 (lane >> 4) .. + 3
+                    *(f32x4*)&ob[r * 128 + ((c ^ (r & 7)) << 4)] = acc[tm][tn];
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -534,7 +534,31 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
 
     // K2a + K3
     {
-        if (s.Ep == 320 && s.Ncat % 64 == 0) {          // A-stationary fast path (E = 300)
+        static const int ipf_kind = getenv("SAD_INPROJ_FWD_WS") == nullptr ? 3 : atoi(getenv("SAD_INPROJ_FWD_WS"));
+        static const int ipf_split2 = getenv("SAD_INPROJ_FWD_SPLIT2") == nullptr ? 0 : atoi(getenv("SAD_INPROJ_FWD_SPLIT2"));
+        static const int ipf_split = getenv("SAD_INPROJ_FWD_SPLIT") == nullptr ? 8 : atoi(getenv("SAD_INPROJ_FWD_SPLIT"));
+        if (ipf_kind == 2 && s.Ep == 320 && s.Ncat % 64 == 0 && s.M > 16384) {   // + loader and store waves
+            constexpr size_t lds = 2 * (32 * 640) + 2 * (256 * 32 * 4);
+            static const hipError_t e_ = hipFuncSetAttribute((const void*)k_inproj_fwd_ws2<10>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)e_;
+            const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 32;
+            const int nsplit = ipf_split < 1 ? 1 : (ipf_split > ntiles ? ntiles : ipf_split);
+            const int nt_per = ceil_div(ntiles, nsplit);
+            hipLaunchKernelGGL((k_inproj_fwd_ws2<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(768), lds, st, s, X, need,
+                               at<bf16raw>(packed, pl.wcat), at<float>(packed, pl.bcat), G, Kk, nt_per);
+        } else if (ipf_kind == 3 && s.Ep == 320 && s.Ncat % 64 == 0) {   // A-stationary + wave-private output turn
+            constexpr size_t lds = 64 * 10 * 64 + 8 * 8192;
+            static const hipError_t e_ = hipFuncSetAttribute((const void*)k_inproj_fwd_rs2<10>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)e_;
+            const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
+            int nsplit = ipf_split2 > 0 ? ipf_split2 : 1024 / mtiles;
+            nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+            const int nt_per = ceil_div(ntiles, nsplit);
+            hipLaunchKernelGGL((k_inproj_fwd_rs2<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(512), lds, st, s, X, need,
+                               at<bf16raw>(packed, pl.wcat), at<float>(packed, pl.bcat), G, Kk, nt_per);
+        } else if (s.Ep == 320 && s.Ncat % 64 == 0) {          // A-stationary fast path (E = 300)
             const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
             int nsplit = 1024 / mtiles;
             nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);

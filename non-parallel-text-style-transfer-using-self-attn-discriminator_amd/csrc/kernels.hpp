@@ -30,13 +30,30 @@ __global__ void k_prep(Shape s, const int* __restrict__ lens_in, unsigned char* 
     len = len < 0 ? 0 : (len > s.T ? s.T : len);
     lens[b] = len;
     unsigned char* mrow = mask + (long long)b * msb;
-    if (guard && s.T > 1) {
-        bool all = true;
-        for (int t = 0; t < s.T; ++t) all = all && (mrow[(long long)t * mst] != 0);
-        if (all) mrow[mst] = 0;
+    // one pass over the mask row in blocks of 64 steps (independent loads, kept as bits); the guard
+    // needs the whole row, so the need bytes of a block are written once the next one is known
+    bool all = true;
+    for (int t0 = 0; t0 < s.T; t0 += 64) {
+        unsigned long long bits = 0;
+        const int n = s.T - t0 < 64 ? s.T - t0 : 64;
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) bits |= (unsigned long long)(mrow[(long long)(t0 + i) * mst] != 0) << i;
+        all = all && (n == 64 ? ~bits == 0ull : bits == ((1ull << n) - 1ull));
     }
-    for (int t = 0; t < s.T; ++t)
-        need[(long long)t * s.B + b] = (unsigned char)((t < len ? 1 : 0) | (mrow[(long long)t * mst] ? 0 : 2));
+    const bool unmask1 = guard && s.T > 1 && all;        // all-masked row: the reference unmasks t = 1
+    if (unmask1) mrow[mst] = 0;
+    for (int t0 = 0; t0 < s.T; t0 += 64) {
+        unsigned long long bits = 0;
+        const int n = s.T - t0 < 64 ? s.T - t0 : 64;
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) bits |= (unsigned long long)(mrow[(long long)(t0 + i) * mst] != 0) << i;
+        if (unmask1 && t0 == 0) bits &= ~2ull;
+#pragma unroll 8
+        for (int i = 0; i < n; ++i) {
+            const int t = t0 + i;
+            need[(long long)t * s.B + b] = (unsigned char)((t < len ? 1 : 0) | (((bits >> i) & 1ull) ? 0 : 2));
+        }
+    }
 }
 
 template <class C>
@@ -342,12 +359,14 @@ __global__ __launch_bounds__(768) void k_softemb_fwd_ws(Shape s, const void* __r
 #define K1P_ACC { for (int i_ = 1; i_ < 4; ++i_) pa_[i_] += pt_[i_] - pt_[i_ - 1]; ++pn_; }
 #define K1P_MFMA { float t_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(t_) : "v"(acc[0][0][0]), "v"(acc[C::TM - 1][C::TN - 1][0])); }
 #define K1P_OUT(what) if (blockIdx.x == SAD_K1F_PROF && lane == 0 && (wave == 0 || wave == 8 || wave == 12)) printf("%s: n=%d  %.3f %.3f %.3f us per k-tile, role total %.1f us\n", what, pn_, pa_[1] / 100.0 / pn_, pa_[2] / 100.0 / pn_, pa_[3] / 100.0 / pn_, (wall_clock64() - t_begin_) / 100.0);
+#define K1P_OUT2(what) if (blockIdx.x == SAD_K1F_PROF && blockIdx.y == 1 && lane == 0 && (wave == 0 || wave == 8 || wave == 10)) printf("%s: n=%d  %.3f %.3f %.3f us per tile, role total %.1f us\n", what, pn_, pa_[1] / 100.0 / pn_, pa_[2] / 100.0 / pn_, pa_[3] / 100.0 / pn_, (wall_clock64() - t_begin_) / 100.0);
 #else
 #define K1P_DECL
 #define K1P_T(i)
 #define K1P_ACC
 #define K1P_MFMA
 #define K1P_OUT(what)
+#define K1P_OUT2(what)
 #endif
 #ifndef SAD_K1F_D
 #define SAD_K1F_D 4
@@ -1937,8 +1956,11 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
             obase[i] = (long long)t * sT + (long long)b * sB;
         }
         const int c = ls & 7;
+        K1P_DECL
         __syncthreads();                                       // prologue barrier
         for (int it = 0; it <= ntl; ++it) {
+            K1P_T(0)
+            K1P_T(1)
             if (it >= 1) {
                 const unsigned char* buf = Os + ((it - 1) & 1) * OUTB;
                 const int n = (nt0 + it - 1) * BN + c * 8;
@@ -1956,8 +1978,12 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
                     }
                 }
             }
+            K1P_T(2)
             __syncthreads();
+            K1P_T(3)
+            K1P_ACC
         }
+        K1P_OUT2("storers: -, LDS reads + store issue, barrier")
         return;
     }
     if (wave >= 8) {
@@ -1988,13 +2014,22 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
         to_lds(0);
         load_tile(1);
         __syncthreads();                                       // prologue barrier: tile 0 ready
+        K1P_DECL
         for (int it = 0; it <= ntl; ++it) {
+            K1P_T(0)
             if (it + 1 < ntl) {
                 to_lds(it + 1);
+                K1P_T(1)
                 load_tile(it + 2);
+            } else {
+                K1P_T(1)
             }
+            K1P_T(2)
             __syncthreads();
+            K1P_T(3)
+            K1P_ACC
         }
+        K1P_OUT2("loaders: to_lds (wait + write), issue, barrier")
         return;
     }
     // ---------------------------------------- compute waves --------------------------------------
@@ -2023,7 +2058,10 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
         rsw[tn] = (rho >> 1) & 7;
     }
     __syncthreads();                                           // prologue barrier
+    K1P_DECL
     for (int it = 0; it <= ntl; ++it) {
+        K1P_T(0)
+        K1P_T(1)
         if (it < ntl) {
             const unsigned char* buf = Bs + (it & 1) * TILEB;
             unsigned char* ob = Os + (it & 1) * OUTB;
@@ -2056,8 +2094,12 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
                 }
             }
         }
+        K1P_T(2)
         __syncthreads();
+        K1P_T(3)
+        K1P_ACC
     }
+    K1P_OUT2("compute: -, MFMA + LDS write, barrier")
 }
 
 // K2a + K3 fast path (Ep == 32*KS, Ncat % 64 == 0): [G | Kk][m] = X[m] . Wcat^T + bcat.

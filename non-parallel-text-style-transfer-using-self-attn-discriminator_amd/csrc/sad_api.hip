@@ -252,7 +252,10 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     // A-stationary fast path for the shipped embedding size (E = 300 -> Ep = 320 = 32*10)
     const bool rs = s.Ep == 320;
     const int mtiles = ceil_div(s.M, 256), ntiles = s.Vp / 64;
-    int vsplit = 1024 / mtiles;                       // ~4 workgroups per CU for dynamic balance
+    // One workgroup per CU is resident at a time (LDS), and every workgroup pays a prologue (dX
+    // fragments, first W tile): one round of ~256 workgroups (measured: 1024 -> 257 us, 256 -> 246 us).
+    static const int k1b_wgs = getenv("SAD_K1B_WGS") == nullptr ? 256 : atoi(getenv("SAD_K1B_WGS"));
+    int vsplit = k1b_wgs / mtiles;
     vsplit = vsplit < 1 ? 1 : (vsplit > ntiles ? ntiles : vsplit);
     const int nt_per = ceil_div(ntiles, vsplit);
     const dim3 rs_grid(mtiles, ceil_div(ntiles, nt_per));

@@ -10,8 +10,15 @@ params = synth.make_params(w["V"], w["E"], w["H"], w["L"], seed=21)
 pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})
 S, lengths, ln_dev, mask, labels = bench.make_inputs(w, 1234, dev)
 Sv = S.transpose(0, 1)
+bwd = bool(os.environ.get("K1_BWD"))
+if bwd:
+    Sv.requires_grad_(True)
 for it in range(2):
-    with torch.no_grad():
-        Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
+    if bwd:
+        loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
+        loss.mean().backward()
+    else:
+        with torch.no_grad():
+            Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
     torch.cuda.synchronize()
     print("----")

@@ -345,3 +345,124 @@ def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, 
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
     logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, drop, *_live(params))
     return loss, logits, weights
+
+
+# ------------------------------------------------------------------------------------------------
+# Sibling soft contractions of the generator: ``soft_tokens @ embedding.weight`` in
+# the decoder step (transfer/models.py:254) and in the content-alignment loss (:1221).  The same GEMM
+# shape as the discriminator's K1 / K1', so the same kernels run it through the stage entry points
+# of the C-ABI (sad_prep with full lengths -> every row needed, sad_softemb_fwd, sad_softemb_bwd,
+# sad_param_grads_accumulate for d weight).
+# ------------------------------------------------------------------------------------------------
+_SE_H, _SE_L = 16, 2          # smallest discriminator shape the layouts accept: only the embedding is used
+_se_cache = {}
+
+
+def _se_packed(weight):
+    """bf16 images of the embedding matrix (both orientations), cached per tensor version."""
+    key = (weight.data_ptr(), tuple(weight.shape), str(weight.device))
+    hit = _se_cache.get(key)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    V, E = weight.shape
+    dev = weight.device
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    H, L = _SE_H, _SE_L
+    params = {"embedding.weight": weight.detach()}
+    for sfx in ("", "_reverse"):
+        params["rnn.weight_ih_l0" + sfx] = z(4 * H, E)
+        params["rnn.weight_hh_l0" + sfx] = z(4 * H, H)
+        params["rnn.bias_ih_l0" + sfx] = z(4 * H)
+        params["rnn.bias_hh_l0" + sfx] = z(4 * H)
+    params.update({"hidden_bridges.0.weight": z(H, 2 * H), "hidden_bridges.0.bias": z(H),
+                   "linear_emb.weight": z(H, E), "linear_emb.bias": z(H), "linear_q.weight": z(H, H),
+                   "linear_q.bias": z(H), "linear_attn.weight": z(1, H), "linear_attn.bias": z(1),
+                   "output_layer.weight": z(L, H), "output_layer.bias": z(L)})
+    pw = PackedWeights(V, E, H, L, dev).pack(params)
+    if len(_se_cache) > 8:
+        _se_cache.clear()
+    _se_cache[key] = (weight._version, pw)
+    return pw
+
+
+class _SoftEmbedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S, weight):
+        if not S.is_cuda or not weight.is_cuda:
+            raise RuntimeError("soft_embedding needs tensors on the HIP device (there is no CPU path)")
+        if weight.dtype != torch.float32 or weight.dim() != 2:
+            raise RuntimeError("weight must be a float32 [V, E] matrix")
+        if S.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("soft tokens must be float32 or bfloat16, got %s" % S.dtype)
+        if S.shape[-1] != weight.shape[0]:
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%s and %s)" % (tuple(S.shape), tuple(weight.shape)))
+        lead = tuple(S.shape[:-1])
+        S3 = S if S.dim() == 3 else S.reshape(-1, 1, S.shape[-1])
+        if S3.stride(2) != 1:
+            S3 = S3.contiguous()
+        # rows are numbered m = t*B + b: the dimension with the larger stride plays "t", so the result
+        # is laid out like the input
+        swap = S3.stride(0) < S3.stride(1)
+        Sv = S3.transpose(0, 1) if swap else S3               # [t][b][V]
+        T, B, V = Sv.shape
+        E = weight.shape[1]
+        dev = S.device
+        pw = _se_packed(weight)
+        d = _lib.dims(B, T, V, E, _SE_H, _SE_L)
+        ws = Workspace(d, dev)
+        kind = _lib.SRC_F32 if S.dtype == torch.float32 else _lib.SRC_BF16
+        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        mask = torch.zeros((B, T), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            lib = _lib.load()
+            _lib.check(lib.sad_prep(ctypes.byref(d), _ptr(lens), _ptr(mask), mask.stride(0), mask.stride(1), 0,
+                                    _ptr(ws.buf), _stream_ptr()), "sad_prep")
+            _lib.check(lib.sad_softemb_fwd(ctypes.byref(d), _ptr(pw.buf), _ptr(Sv), kind, Sv.stride(1), Sv.stride(0),
+                                           _ptr(ws.buf), _stream_ptr()), "sad_softemb_fwd")
+        Ep = _lib.padded_dims(d)["Ep"]
+        X = ws.view("X", torch.bfloat16)[:T * B * Ep].view(T, B, Ep)[:, :, :E].to(S.dtype)
+        ctx.save_for_backward(Sv, weight)
+        ctx.meta = (d, ws, pw, kind, swap, lead, Ep)
+        out = X.transpose(0, 1) if swap else X
+        return out.reshape(lead + (E,))
+
+    @staticmethod
+    def backward(ctx, dout):
+        Sv, weight = ctx.saved_tensors
+        d, ws, pw, kind, swap, lead, Ep = ctx.meta
+        T, B, V = Sv.shape
+        E = weight.shape[1]
+        dev = Sv.device
+        g3 = dout.reshape((B, T, E) if swap else (T, B, E))
+        if swap:
+            g3 = g3.transpose(0, 1)
+        dx = ws.view("DX", torch.bfloat16)[:T * B * Ep].view(T, B, Ep)
+        dx[:, :, :E] = g3
+        if Ep > E:
+            dx[:, :, E:] = 0
+        dS = dW = None
+        with torch.cuda.device(dev):
+            lib = _lib.load()
+            if ctx.needs_input_grad[0]:
+                dSv = torch.empty_strided(Sv.shape, Sv.stride(), dtype=Sv.dtype, device=dev) if _is_dense(
+                    tuple(Sv.shape), tuple(Sv.stride())) else torch.empty(Sv.shape, dtype=Sv.dtype, device=dev)
+                _lib.check(lib.sad_softemb_bwd(ctypes.byref(d), _ptr(pw.buf), _ptr(dSv), kind, dSv.stride(1), dSv.stride(0),
+                                               _ptr(ws.buf), _stream_ptr()), "sad_softemb_bwd")
+                dS = (dSv.transpose(0, 1) if swap else dSv).reshape(lead + (V,))
+            if ctx.needs_input_grad[1]:
+                dW = torch.zeros((V, E), dtype=torch.float32, device=dev)
+                g = _lib.SadParamGrads()
+                g.embedding_weight = dW.data_ptr()
+                _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d), ctypes.byref(g), _ptr(Sv), kind, Sv.stride(1),
+                                                          Sv.stride(0), -1, _ptr(ws.buf), _stream_ptr()),
+                           "sad_param_grads_accumulate")
+        return dS, dW
+
+
+def soft_embedding(soft_tokens, weight):
+    """``soft_tokens @ weight`` for soft tokens ``[..., V]`` (float32 or bfloat16, unit stride along V)
+    and an embedding matrix ``[V, E]`` (float32), differentiable in both — the generator's sibling
+    contractions of the discriminator's soft branch (reference transfer/models.py:254 decoder step,
+    :1221 content alignment).  bf16 MFMA inputs, fp32 accumulation; the result is rounded to bf16
+    once (the kernels' activation format) and returned in the dtype of ``soft_tokens``."""
+    return _SoftEmbedding.apply(soft_tokens, weight)

@@ -79,3 +79,13 @@ def test_cpu_tensors_are_refused():
         V, E, H, L = 50, 8, 8, 2
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Fn.discriminator(torch.zeros(2, 3, 50), torch.tensor([3, 2]), torch.zeros(2, 3, dtype=torch.bool), FakePW())
+
+
+def test_soft_embedding_has_no_cpu_path():
+    """The sibling contraction runs on the HIP kernels only: CPU tensors are refused."""
+    import pytest
+    import torch
+    from sad_amd import functional as Fn
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Fn.soft_embedding(torch.rand(2, 3, 7), torch.rand(7, 4))
+

@@ -555,6 +555,47 @@ def test_large_batch_dense_soft_tokens_vs_oracle():
         assert errs["dS"] < BF16_TOL_BWD * 1.5
 
 
+def test_soft_embedding_sibling_contractions():
+    """``soft_tokens @ embedding.weight`` as the generator calls it — one decoder step
+    ``[1,B,V]`` (transfer/models.py:254), the content-alignment product on ``[T,B,V]`` (:1221), a
+    batch-major strided view and a plain 2-D matrix; fp32 and bf16 soft tokens.  Forward, d soft_tokens
+    and d weight against the fp64 product of the bf16-rounded operands (stated bf16 tolerance)."""
+    import torch
+    from sad_amd import functional as Fn
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    V, E = 1111, 300
+    W = (rng.standard_normal((V, E)) * 0.05).astype(np.float32)
+    cases = [("decoder step", (1, 64, V), False), ("content align", (30, 640, V), False),
+             ("batch-major view", (30, 96, V), True), ("matrix", (257, V), False)]
+    for name, shape, as_view in cases:
+        for dtype in (torch.float32, torch.bfloat16):
+            logits = rng.standard_normal(shape).astype(np.float32) * 2.0
+            S_np = np.exp(logits - logits.max(-1, keepdims=True))
+            S_np = bf16_round((S_np / S_np.sum(-1, keepdims=True)).astype(np.float32))
+            G_np = rng.standard_normal(shape[:-1] + (E,)).astype(np.float32)
+            S = torch.from_numpy(S_np).to(dev).to(dtype)
+            if as_view:      # storage [T,B,V], handed over as [B,T,V]
+                S = S.transpose(0, 1)
+                S_np, G_np = S_np.swapaxes(0, 1), G_np.swapaxes(0, 1)
+            S = S.detach().requires_grad_(True)
+            Wt = torch.from_numpy(W).to(dev).requires_grad_(True)
+            out = Fn.soft_embedding(S, Wt)
+            assert tuple(out.shape) == tuple(S_np.shape[:-1]) + (E,) and out.dtype == dtype
+            out.backward(torch.from_numpy(np.ascontiguousarray(G_np)).to(dev).to(dtype))
+            Wb, Gb = bf16_round(W).astype(np.float64), bf16_round(G_np).astype(np.float64)
+            S64 = S_np.astype(np.float64)
+            ref = S64 @ Wb
+            ref_dS = Gb @ Wb.T
+            ref_dW = S64.reshape(-1, V).T @ Gb.reshape(-1, E)
+            errs = dict(out=relerr(out.detach().float().cpu().numpy(), ref),
+                        dS=relerr(S.grad.float().cpu().numpy(), ref_dS),
+                        dW=relerr(Wt.grad.cpu().numpy(), ref_dW))
+            _report("soft_embedding %s %s" % (name, str(dtype).split(".")[-1]), errs)
+            assert errs["out"] < 6e-3 and errs["dS"] < 1e-2 and errs["dW"] < 1e-2, (name, dtype, errs)
+            assert S.grad.stride() == S.stride() or not as_view
+
+
 def test_ragged_and_edge_shapes():
     """Edge cases: B=1, all lengths equal to T, len==2 rows (all-masked guard), a batch and T that
     are not multiples of any tile size, unsorted lengths given on the device (no host check)."""

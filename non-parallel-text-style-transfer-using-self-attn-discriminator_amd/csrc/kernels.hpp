@@ -854,36 +854,48 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
 
 // Adds the slabs of every row tile that k_softemb_fwd_sk split over workgroups (in workgroup order) and
 // writes its bf16 X rows.  Same unit partition (nwg = the stream-K grid).  One wave per block:
-// block (ti, w) takes the accumulator fragments of compute wave w, all loads of a slab in flight.
+// block (ti, w, tm) takes the accumulator fragments of row fragment tm of compute wave w (many small
+// blocks: the kernel is a latency chain of a few dependent loads).
 __global__ __launch_bounds__(64) void k_softemb_fwd_fix(Shape s, const int* __restrict__ tiles, int nwg,
                                                        const float* __restrict__ slabs, bf16raw* __restrict__ X) {
     typedef Cfg<128, 320, 2, 4, 1> C;
+    static_assert(C::TN == 5 && C::TM == 4, "one block per (tile, compute wave, row fragment)");
     const int ti = blockIdx.x;
     if (ti >= tiles[0]) return;
     const int nk = (s.V + 63) / 64;
     const int sx = k1_sixteenths(tiles[0], nwg);
     const int g0 = k1_wg_of((long long)ti * nk, sx, nk), g1 = k1_wg_of((long long)(ti + 1) * nk - 1, sx, nk);
     if (g0 == g1) return;                                      // one workgroup had the whole tile: stored directly
-    const int lane = threadIdx.x, wave = blockIdx.y;
+    const int lane = threadIdx.x, wave = blockIdx.y, tm = blockIdx.z;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int m0 = tiles[1 + ti] * 128;
-    f32x4 v[C::TM * C::TN];
+    f32x4 v[C::TN];
 #pragma unroll
-    for (int i = 0; i < C::TM * C::TN; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int g = g0; g <= g1; ++g) {
-        const int slot = (int)(k1_u0(g, sx, nk) / nk) == ti ? 0 : 1;
-        const float* slab = slabs + ((long long)g * 2 + slot) * K1_SLAB_FLOATS + (long long)wave * (C::TM * C::TN * 256);
+    for (int i = 0; i < C::TN; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // four slabs' loads in flight at a time (small batches: up to 16 slabs per tile); added in workgroup order
+    for (int g = g0; g <= g1; g += 4) {
+        f32x4 w[4][C::TN];
 #pragma unroll
-        for (int i = 0; i < C::TM * C::TN; ++i) v[i] += *(const f32x4*)&slab[(i * 64 + lane) * 4];
-    }
+        for (int j = 0; j < 4; ++j) {
+            const int gj = g + j <= g1 ? g + j : g1;           // clamped: loads are never skipped
+            const int slot = (int)(k1_u0(gj, sx, nk) / nk) == ti ? 0 : 1;
+            const float* slab = slabs + ((long long)gj * 2 + slot) * K1_SLAB_FLOATS + (long long)wave * (C::TM * C::TN * 256);
 #pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        const int m = m0 + frag_row<C>(wm, tm, lane);
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int nn = frag_col<C>(wn, tn, lane);
-            if (m < s.M && nn < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + nn] = pack_bf16x4(v[tm * C::TN + tn]);
+            for (int i = 0; i < C::TN; ++i) w[j][i] = *(const f32x4*)&slab[((tm * C::TN + i) * 64 + lane) * 4];
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            // short k ranges (nk < 16) leave some workgroups without units: they wrote no slab
+            if (g + j <= g1 && k1_u0(g + j, sx, nk) < k1_u0(g + j + 1, sx, nk)) {
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) v[i] += w[j][i];
+            }
+    }
+    const int m = m0 + frag_row<C>(wm, tm, lane);
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const int nn = frag_col<C>(wn, tn, lane);
+        if (m < s.M && nn < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + nn] = pack_bf16x4(v[tn]);
     }
 }
 

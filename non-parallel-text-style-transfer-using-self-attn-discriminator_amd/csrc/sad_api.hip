@@ -95,7 +95,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
     w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
     w.bytes[SAD_WS_HX] = lstm_fwd_xchg_bytes(s.B, s.Hp);
-    const bool k1_sk = s.Ep == 320 && s.M > 16384;          // the stream-K form of K1 (run_softemb_fwd)
+    const bool k1_sk = s.Ep == 320;                          // the stream-K form of K1 (run_softemb_fwd) and of K2a'+K3'
     w.bytes[SAD_WS_K1TILES] = k1_sk ? ((size_t)ceil_div(s.M, 128) + 4) * 4 : 0;
     w.bytes[SAD_WS_K1SLABS] = k1_sk ? (size_t)K1_MAX_WGS * 2 * K1_SLAB_FLOATS * 4 : 0;
     size_t o = 0;
@@ -188,7 +188,7 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles (measured: B=64 166 -> 93 us, B=1024 302 -> 417 us)
     static const bool fwd_ws = getenv("SAD_K1F_WS") == nullptr || atoi(getenv("SAD_K1F_WS")) != 0;   // A/B switch
     static const int fwd_ws_kind = getenv("SAD_K1F_WS") == nullptr ? 4 : atoi(getenv("SAD_K1F_WS"));
-    if (fwd_ws && s.Ep == 320 && !small_m && (kind == SAD_SRC_F32 || kind == SAD_SRC_BF16)) {
+    if (fwd_ws && s.Ep == 320 && (!small_m || fwd_ws_kind >= 4) && s.V >= 64 && (kind == SAD_SRC_F32 || kind == SAD_SRC_BF16)) {
         if (check_aligned(src, kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
         const dim3 grid(ceil_div(s.M, 128));
 #define SAD_K1F_LAUNCH(KERNEL, LDS, THREADS)                                                                             \
@@ -215,7 +215,7 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
             if (kind == SAD_SRC_F32) SAD_K1SK_LAUNCH(k_softemb_fwd_sk<SRC_F32>)
             else SAD_K1SK_LAUNCH(k_softemb_fwd_sk<SRC_BF16>)
 #undef SAD_K1SK_LAUNCH
-            hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8), dim3(64), 0, st, s, tiles, nwg, slabs, X);
+            hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8, 4), dim3(64), 0, st, s, tiles, nwg, slabs, X);
         } else if (fwd_ws_kind == 3) {     // S and W loader waves apart (deep S prefetch, LDS-direct W)
             if (kind == SAD_SRC_F32) SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_F32>, lds3, 1024)
             else SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_BF16>, lds3, 1024)
@@ -712,13 +712,13 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
         // runs on K1's pipelined kernels with a patched shape: 3 = three wave roles, 4 = + stream-K
         // (SAD_INPROJ_BWD_WS=0: the single-role kernel; A/B switch).
         static const int ws_kind = getenv("SAD_INPROJ_BWD_WS") == nullptr ? 3 : atoi(getenv("SAD_INPROJ_BWD_WS"));
-        if (ws_kind >= 3 && s.Ep == 320 && s.M > 16384 && s.Ncat % 64 == 0 && wl.bytes[SAD_WS_K1SLABS] != 0) {
+        if (ws_kind >= 3 && s.Ep == 320 && s.Ncat % 64 == 0 && wl.bytes[SAD_WS_K1SLABS] != 0) {
             Shape sp = s;
             sp.V = s.Ncat;
             sp.Vp = s.Ncat;
             constexpr size_t lds3 = 2 * 128 * 128 + 3 * 320 * 128;
             const bf16raw* wT = at<bf16raw>(packed, pl.wcatT);
-            if (ws_kind >= 4) {
+            if (ws_kind >= 4 || s.M < 16384) {       // few row tiles: stream-K fills the CUs (deterministic, no atomics)
                 int* tiles = at<int>(ws, wl.off[SAD_WS_K1TILES]);
                 float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
                 int dev = 0, cus = 0;
@@ -731,7 +731,7 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
                 (void)e_;
                 hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_BF16>, dim3(nwg), dim3(1024), lds3, st, sp, (const void*)DZ,
                                    (long long)s.B * s.Ncat, (long long)s.Ncat, need, tiles, wT, DX, slabs);
-                hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8), dim3(64), 0, st, sp, tiles, nwg, slabs, DX);
+                hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8, 4), dim3(64), 0, st, sp, tiles, nwg, slabs, DX);
             } else {
                 static const hipError_t e_ = hipFuncSetAttribute((const void*)k_softemb_fwd_ws3<SRC_BF16>,
                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds3);

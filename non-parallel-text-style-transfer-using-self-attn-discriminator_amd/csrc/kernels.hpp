@@ -2417,4 +2417,37 @@ __global__ void k_pack(OutT* __restrict__ dst, int rows, int cols, long long ldd
     }
 }
 
+// All packing jobs of sad_pack_weights in ONE launch (28 separate launches cost ~140 us per weight
+// re-pack, which the unfrozen mode pays every optimizer step).  blockIdx.y = job.
+struct PackJob {
+    void* dst;
+    const float* src;
+    const float* src2;
+    long long ldd, lds;
+    IdxMap rmap, cmap;
+    int rows, cols, tr, bf16;
+};
+constexpr int PACK_MAX_JOBS = 32;
+struct PackJobs {
+    PackJob j[PACK_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void k_pack_all(PackJobs jobs) {
+    const PackJob& J = jobs.j[blockIdx.y];
+    const long long total = (long long)J.rows * J.cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / J.cols), c = (int)(i - (long long)r * J.cols);
+        const int a = map_idx(J.rmap, r), bb = map_idx(J.cmap, c);
+        float v = 0.f;
+        if (a >= 0 && bb >= 0) {
+            const long long si = J.tr ? (long long)bb * J.lds + a : (long long)a * J.lds + bb;
+            v = J.src[si];
+            if (J.src2 != nullptr) v += J.src2[si];
+        }
+        if (J.bf16)
+            ((bf16raw*)J.dst)[(long long)r * J.ldd + c] = f32_to_bf16(v);
+        else
+            ((float*)J.dst)[(long long)r * J.ldd + c] = v;
+    }
+}
+
 }  // namespace sad

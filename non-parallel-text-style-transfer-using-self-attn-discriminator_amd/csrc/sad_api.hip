@@ -354,14 +354,35 @@ bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid);
 }
 
+// sad_pack_weights collects its jobs here and launches them together (k_pack_all)
+struct PackBatch {
+    PackJobs jobs;
+    int n = 0;
+    long long biggest = 0;
+};
 template <typename OutT>
-void launch_pack(OutT* dst, int rows, int cols, long long ldd, const float* src, const float* src2, long long lds,
-                 IdxMap rmap, IdxMap cmap, int tr, hipStream_t st) {
+void launch_pack(PackBatch& pb, OutT* dst, int rows, int cols, long long ldd, const float* src, const float* src2,
+                 long long lds, IdxMap rmap, IdxMap cmap, int tr) {
+    PackJob& J = pb.jobs.j[pb.n++];
+    J.dst = dst;
+    J.src = src;
+    J.src2 = src2;
+    J.ldd = ldd;
+    J.lds = lds;
+    J.rmap = rmap;
+    J.cmap = cmap;
+    J.rows = rows;
+    J.cols = cols;
+    J.tr = tr;
+    J.bf16 = sizeof(OutT) == 2;
     const long long total = (long long)rows * cols;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    if (total > pb.biggest) pb.biggest = total;
+}
+void run_pack(PackBatch& pb, hipStream_t st) {
+    int blocks = (int)((pb.biggest + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_pack<OutT>), dim3(blocks), dim3(256), 0, st, dst, rows, cols, ldd, src, src2, lds, rmap, cmap, tr);
+    hipLaunchKernelGGL(k_pack_all, dim3(blocks, pb.n), dim3(256), 0, st, pb.jobs);
 }
 
 }  // namespace
@@ -416,41 +437,44 @@ int sad_pack_weights(const sad_dims* d, const sad_weights* w, void* packed, void
     const IdxMap idE{MAP_ID, s.E, s.H, s.Hp}, idV{MAP_ID, s.V, s.H, s.Hp}, idH{MAP_ID, s.H, s.H, s.Hp};
     const IdxMap idL{MAP_ID, s.L, s.H, s.Hp}, id1{MAP_ID, 1, s.H, s.Hp};
     const IdxMap gate{MAP_GATE, 0, s.H, s.Hp}, hcat{MAP_HCAT, 0, s.H, s.Hp};
+    PackBatch pb;
     // embedding: [Ep][Vp] (K1's Bt) and [Vp][Ep] (K1' Bt, and the hard-token gather table)
-    launch_pack(at<bf16raw>(packed, p.wembT), s.Ep, s.Vp, s.Vp, w->embedding_weight, nullptr, s.E, idE, idV, 1, st);
-    launch_pack(at<bf16raw>(packed, p.wemb), s.Vp, s.Ep, s.Ep, w->embedding_weight, nullptr, s.E, idV, idE, 0, st);
+    launch_pack(pb, at<bf16raw>(packed, p.wembT), s.Ep, s.Vp, s.Vp, w->embedding_weight, nullptr, s.E, idE, idV, 1);
+    launch_pack(pb, at<bf16raw>(packed, p.wemb), s.Vp, s.Ep, s.Ep, w->embedding_weight, nullptr, s.E, idV, idE, 0);
     // fused in-projection [Ncat][Ep], its transpose [Ep][Ncat], bias [Ncat]
     for (int dir = 0; dir < 2; ++dir) {
-        launch_pack(at<bf16raw>(packed, p.wcat) + (size_t)dir * s.Gp * s.Ep, s.Gp, s.Ep, s.Ep, w->rnn_weight_ih[dir],
-                    nullptr, s.E, gate, idE, 0, st);
-        launch_pack(at<bf16raw>(packed, p.wcatT) + (size_t)dir * s.Gp, s.Ep, s.Gp, s.Ncat, w->rnn_weight_ih[dir],
-                    nullptr, s.E, idE, gate, 1, st);
-        launch_pack(at<float>(packed, p.bcat) + (size_t)dir * s.Gp, 1, s.Gp, s.Gp, w->rnn_bias_ih[dir],
-                    w->rnn_bias_hh[dir], 4 * s.H, id1, gate, 0, st);
-        launch_pack(at<bf16raw>(packed, p.whh) + (size_t)dir * s.Gp * s.Hp, s.Gp, s.Hp, s.Hp, w->rnn_weight_hh[dir],
-                    nullptr, s.H, gate, idH, 0, st);
-        launch_pack(at<bf16raw>(packed, p.whhT) + (size_t)dir * s.Hp * s.Gp, s.Hp, s.Gp, s.Gp, w->rnn_weight_hh[dir],
-                    nullptr, s.H, idH, gate, 1, st);
+        launch_pack(pb, at<bf16raw>(packed, p.wcat) + (size_t)dir * s.Gp * s.Ep, s.Gp, s.Ep, s.Ep, w->rnn_weight_ih[dir],
+                    nullptr, s.E, gate, idE, 0);
+        launch_pack(pb, at<bf16raw>(packed, p.wcatT) + (size_t)dir * s.Gp, s.Ep, s.Gp, s.Ncat, w->rnn_weight_ih[dir],
+                    nullptr, s.E, idE, gate, 1);
+        launch_pack(pb, at<float>(packed, p.bcat) + (size_t)dir * s.Gp, 1, s.Gp, s.Gp, w->rnn_bias_ih[dir],
+                    w->rnn_bias_hh[dir], 4 * s.H, id1, gate, 0);
+        launch_pack(pb, at<bf16raw>(packed, p.whh) + (size_t)dir * s.Gp * s.Hp, s.Gp, s.Hp, s.Hp, w->rnn_weight_hh[dir],
+                    nullptr, s.H, gate, idH, 0);
+        launch_pack(pb, at<bf16raw>(packed, p.whhT) + (size_t)dir * s.Hp * s.Gp, s.Hp, s.Gp, s.Gp, w->rnn_weight_hh[dir],
+                    nullptr, s.H, idH, gate, 1);
     }
-    launch_pack(at<bf16raw>(packed, p.wcat) + (size_t)2 * s.Gp * s.Ep, s.Hp, s.Ep, s.Ep, w->linear_emb_weight, nullptr,
-                s.E, idH, idE, 0, st);
-    launch_pack(at<bf16raw>(packed, p.wcatT) + (size_t)2 * s.Gp, s.Ep, s.Hp, s.Ncat, w->linear_emb_weight, nullptr, s.E,
-                idE, idH, 1, st);
-    launch_pack(at<float>(packed, p.bcat) + (size_t)2 * s.Gp, 1, s.Hp, s.Hp, w->linear_emb_bias, nullptr, s.H, id1, idH,
-                0, st);
+    launch_pack(pb, at<bf16raw>(packed, p.wcat) + (size_t)2 * s.Gp * s.Ep, s.Hp, s.Ep, s.Ep, w->linear_emb_weight, nullptr,
+                s.E, idH, idE, 0);
+    launch_pack(pb, at<bf16raw>(packed, p.wcatT) + (size_t)2 * s.Gp, s.Ep, s.Hp, s.Ncat, w->linear_emb_weight, nullptr, s.E,
+                idE, idH, 1);
+    launch_pack(pb, at<float>(packed, p.bcat) + (size_t)2 * s.Gp, 1, s.Hp, s.Hp, w->linear_emb_bias, nullptr, s.H, id1, idH,
+                0);
     // hidden_bridges[0]: [Hp][2Hp] over k = [h_fwd | h_rev], and its transpose
-    launch_pack(at<bf16raw>(packed, p.whb0), s.Hp, 2 * s.Hp, 2 * s.Hp, w->hidden_bridge0_weight, nullptr, 2 * s.H, idH,
-                hcat, 0, st);
-    launch_pack(at<bf16raw>(packed, p.whb0T), 2 * s.Hp, s.Hp, s.Hp, w->hidden_bridge0_weight, nullptr, 2 * s.H, hcat,
-                idH, 1, st);
-    launch_pack(at<float>(packed, p.bhb0), 1, s.Hp, s.Hp, w->hidden_bridge0_bias, nullptr, s.H, id1, idH, 0, st);
-    launch_pack(at<bf16raw>(packed, p.wq), s.Hp, s.Hp, s.Hp, w->linear_q_weight, nullptr, s.H, idH, idH, 0, st);
-    launch_pack(at<bf16raw>(packed, p.wqT), s.Hp, s.Hp, s.Hp, w->linear_q_weight, nullptr, s.H, idH, idH, 1, st);
-    launch_pack(at<float>(packed, p.bq), 1, s.Hp, s.Hp, w->linear_q_bias, nullptr, s.H, id1, idH, 0, st);
-    launch_pack(at<float>(packed, p.wa), 1, s.Hp, s.Hp, w->linear_attn_weight, nullptr, s.H, id1, idH, 0, st);
-    launch_pack(at<float>(packed, p.ba), 1, 1, 1, w->linear_attn_bias, nullptr, 1, id1, id1, 0, st);
-    launch_pack(at<float>(packed, p.wo), s.L, s.Hp, s.Hp, w->output_layer_weight, nullptr, s.H, idL, idH, 0, st);
-    launch_pack(at<float>(packed, p.bo), 1, s.L, s.L, w->output_layer_bias, nullptr, s.L, id1, idL, 0, st);
+    launch_pack(pb, at<bf16raw>(packed, p.whb0), s.Hp, 2 * s.Hp, 2 * s.Hp, w->hidden_bridge0_weight, nullptr, 2 * s.H, idH,
+                hcat, 0);
+    launch_pack(pb, at<bf16raw>(packed, p.whb0T), 2 * s.Hp, s.Hp, s.Hp, w->hidden_bridge0_weight, nullptr, 2 * s.H, hcat,
+                idH, 1);
+    launch_pack(pb, at<float>(packed, p.bhb0), 1, s.Hp, s.Hp, w->hidden_bridge0_bias, nullptr, s.H, id1, idH, 0);
+    launch_pack(pb, at<bf16raw>(packed, p.wq), s.Hp, s.Hp, s.Hp, w->linear_q_weight, nullptr, s.H, idH, idH, 0);
+    launch_pack(pb, at<bf16raw>(packed, p.wqT), s.Hp, s.Hp, s.Hp, w->linear_q_weight, nullptr, s.H, idH, idH, 1);
+    launch_pack(pb, at<float>(packed, p.bq), 1, s.Hp, s.Hp, w->linear_q_bias, nullptr, s.H, id1, idH, 0);
+    launch_pack(pb, at<float>(packed, p.wa), 1, s.Hp, s.Hp, w->linear_attn_weight, nullptr, s.H, id1, idH, 0);
+    launch_pack(pb, at<float>(packed, p.ba), 1, 1, 1, w->linear_attn_bias, nullptr, 1, id1, id1, 0);
+    launch_pack(pb, at<float>(packed, p.wo), s.L, s.Hp, s.Hp, w->output_layer_weight, nullptr, s.H, idL, idH, 0);
+    launch_pack(pb, at<float>(packed, p.bo), 1, s.L, s.L, w->output_layer_bias, nullptr, s.L, id1, idL, 0);
+    static_assert(PACK_MAX_JOBS >= 28, "job table too small");
+    run_pack(pb, st);
     SAD_CHECK_LAUNCH("k_pack");
     return 0;
 }
@@ -868,11 +892,10 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     // LSTM biases and linear_emb.bias: column sums of DZ
     if (g->rnn_bias_ih[0] != nullptr || g->rnn_bias_ih[1] != nullptr || g->rnn_bias_hh[0] != nullptr ||
         g->rnn_bias_hh[1] != nullptr || g->linear_emb_bias != nullptr) {
-        const int cb = ceil_div(s.Ncat, 256);
-        int zs = ceil_div(2048, cb);
-        if (zs > ceil_div(s.M, 32)) zs = ceil_div(s.M, 32);
-        const int chunk = ceil_div(s.M, zs);
-        hipLaunchKernelGGL(k_colsum_dz, dim3(cb, ceil_div(s.M, chunk)), dim3(128), 0, st, s, DZ, chunk, g->rnn_bias_ih[0],
+        const int cb = ceil_div(s.Ncat, 1024);
+        int zs = ceil_div(512, cb);                         // row splits (whole 64-row pieces of the compacted list)
+        if (zs > ceil_div(s.M, 64)) zs = ceil_div(s.M, 64);
+        hipLaunchKernelGGL(k_colsum_dz, dim3(cb, zs), dim3(128), 0, st, s, DZ, rows, nrows, g->rnn_bias_ih[0],
                            g->rnn_bias_hh[0], g->rnn_bias_ih[1], g->rnn_bias_hh[1], g->linear_emb_bias);
         SAD_CHECK_LAUNCH("k_colsum_dz");
     }
@@ -895,8 +918,8 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     {
         auto colsum = [&](const float* srcp, int cols, int ld, float* dst) {
             if (dst == nullptr) return;
-            int zs = ceil_div(s.B, 64);
-            if (zs > 64) zs = 64;
+            int zs = ceil_div(s.B, 16);          // short serial sums: the kernel is a latency chain
+            if (zs > 256) zs = 256;
             const int chunk = ceil_div(s.B, zs);
             hipLaunchKernelGGL(k_colsum_f32, dim3(ceil_div(cols, 256), ceil_div(s.B, chunk)), dim3(256), 0, st, srcp, s.B, cols,
                                ld, chunk, dst);
@@ -907,8 +930,8 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         colsum(DSSUM, 1, 1, g->linear_attn_bias);
         colsum(DL, s.L, s.L, g->output_layer_bias);
         if (g->output_layer_weight != nullptr) {
-            int zs = ceil_div(s.B, 64);
-            if (zs > 64) zs = 64;
+            int zs = ceil_div(s.B, 16);
+            if (zs > 256) zs = 256;
             const int chunk = ceil_div(s.B, zs);
             hipLaunchKernelGGL(k_wgrad_head, dim3(ceil_div(s.H, 256), ceil_div(s.B, chunk)), dim3(256), 0, st, s, DL, CTX, chunk,
                                g->output_layer_weight);

@@ -568,31 +568,36 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_dense(Shape s, const float* __r
 // k_colsum_dz: DZ [M][Ncat] bf16 -> d rnn.bias_ih/hh (both get the same sum, nn.LSTM adds the two
 // biases) and d linear_emb.bias.  grid: (Ncat/256, row splits), 128 threads x 2 columns.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_colsum_dz(Shape s, const bf16raw* __restrict__ DZ, int mchunk,
+__global__ __launch_bounds__(128) void k_colsum_dz(Shape s, const bf16raw* __restrict__ DZ,
+                                                  const int* __restrict__ rows, const int* __restrict__ nrows,
                                                   float* __restrict__ bih0, float* __restrict__ bhh0,
                                                   float* __restrict__ bih1, float* __restrict__ bhh1,
                                                   float* __restrict__ blin) {
-    const int n = blockIdx.x * 256 + threadIdx.x * 2;
+    // 8 columns per lane (16-byte loads), only the contributing rows (compacted list), 8 rows in flight;
+    // few row splits: every split costs an atomic add per column onto the same few addresses
+    const int n = blockIdx.x * 1024 + threadIdx.x * 8;
     if (n >= s.Ncat) return;
-    const int m_begin = blockIdx.y * mchunk, m_end = min(s.M, m_begin + mchunk);
-    float a0 = 0.f, a1 = 0.f, c0 = 0.f, c1 = 0.f;
-    int m = m_begin;
-    for (; m + 1 < m_end; m += 2) {                 // two independent chains
-        const unsigned u = *(const unsigned*)(DZ + (long long)m * s.Ncat + n);
-        const unsigned w = *(const unsigned*)(DZ + (long long)(m + 1) * s.Ncat + n);
-        a0 += bf16_to_f32((bf16raw)(u & 0xffffu));
-        a1 += bf16_to_f32((bf16raw)(u >> 16));
-        c0 += bf16_to_f32((bf16raw)(w & 0xffffu));
-        c1 += bf16_to_f32((bf16raw)(w >> 16));
-    }
-    if (m < m_end) {
-        const unsigned u = *(const unsigned*)(DZ + (long long)m * s.Ncat + n);
-        a0 += bf16_to_f32((bf16raw)(u & 0xffffu));
-        a1 += bf16_to_f32((bf16raw)(u >> 16));
-    }
-    const float sum[2] = {a0 + c0, a1 + c1};
+    int j_begin, j_end;
+    if (!wgrad_slice(nrows[ROWS_ANY], blockIdx.y, gridDim.y, &j_begin, &j_end)) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add = [&](u32x4 v) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 4; ++e) {
+            a[2 * e] += bf16_to_f32((bf16raw)(v[e] & 0xffffu));
+            a[2 * e + 1] += bf16_to_f32((bf16raw)(v[e] >> 16));
+        }
+    };
+    int j = j_begin;
+    for (; j + 7 < j_end; j += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *(const u32x4*)(DZ + (long long)rows[j + i] * s.Ncat + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) add(v[i]);
+    }
+    for (; j < j_end; ++j) add(*(const u32x4*)(DZ + (long long)rows[j] * s.Ncat + n));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
         const int col = n + e;
         if (col < 2 * s.Gp) {
             const int dir = col >= s.Gp ? 1 : 0;
@@ -600,11 +605,11 @@ __global__ __launch_bounds__(128) void k_colsum_dz(Shape s, const bf16raw* __res
             if (row < 0) continue;
             float* bi = dir ? bih1 : bih0;
             float* bh = dir ? bhh1 : bhh0;
-            if (bi != nullptr) unsafeAtomicAdd(bi + row, sum[e]);
-            if (bh != nullptr) unsafeAtomicAdd(bh + row, sum[e]);
+            if (bi != nullptr) unsafeAtomicAdd(bi + row, a[e]);
+            if (bh != nullptr) unsafeAtomicAdd(bh + row, a[e]);
         } else {
-            const int j = col - 2 * s.Gp;
-            if (j < s.H && blin != nullptr) unsafeAtomicAdd(blin + j, sum[e]);
+            const int j2 = col - 2 * s.Gp;
+            if (j2 < s.H && blin != nullptr) unsafeAtomicAdd(blin + j2, a[e]);
         }
     }
 }
@@ -616,6 +621,7 @@ __global__ __launch_bounds__(256) void k_colsum_f32(const float* __restrict__ sr
     if (c >= cols) return;
     const int r0 = blockIdx.y * rchunk, r1 = min(rows, r0 + rchunk);
     float a = 0.f;
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) a += src[(long long)r * ld + c];
     unsafeAtomicAdd(dst + c, a);
 }
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(256) void k_wgrad_head(Shape s, const float* __rest
     const int r0 = blockIdx.y * rchunk, r1 = min(s.B, r0 + rchunk);
     for (int c = 0; c < s.L; ++c) {
         float a = 0.f;
+#pragma unroll 8
         for (int b = r0; b < r1; ++b) a += DL[(long long)b * s.L + c] * CTX[(long long)b * s.Hp + h];
         unsafeAtomicAdd(gwo + (long long)c * s.H + h, a);
     }

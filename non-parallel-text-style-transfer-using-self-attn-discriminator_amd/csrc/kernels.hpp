@@ -1112,15 +1112,24 @@ __global__ __launch_bounds__(C::NT) void k_linear(Shape s, int Mrows, int N, int
     } else {
         const bf16raw* Hs = (const bf16raw*)A;
         const int Hp = s.Hp, B = s.B;
+        // the two source rows of every staging chunk of this thread, resolved once: looking lens[b] up
+        // inside the loader put a dependent load in front of every k-tile's loads
+        const bf16raw* rowp[C::ACH][2];
+        bool rowok[C::ACH];
+#pragma unroll
+        for (int i = 0; i < C::ACH; ++i) {
+            const int b = m0 + tid / C::CH + i * C::RSTEP;
+            const int len = b < Mrows ? lens[b] : 0;
+            rowok[i] = len > 0;
+            const int bb = rowok[i] ? b : 0, ts = rowok[i] ? len - 1 : 0;
+            rowp[i][0] = Hs + (((long long)ts * B + bb) * 2 + 0) * Hp;
+            rowp[i][1] = Hs + (((long long)0 * B + bb) * 2 + 1) * Hp;
+        }
         gemm_core<C, u32x4>(
             K,
-            [&](int, int r, int k) {
-                const int b = m0 + r;
+            [&](int i, int, int k) {
                 const int d = k >= Hp ? 1 : 0, kk = k - d * Hp;
-                const int len = b < Mrows ? lens[b] : 0;
-                const bool ok = len > 0 && k < K;
-                const int ts = d ? 0 : len - 1;
-                return load_row(Hs + (((long long)ts * B + b) * 2 + d) * Hp, ok, Hs, kk);
+                return load_row(d ? rowp[i][1] : rowp[i][0], rowok[i] && k < K, Hs, kk);
             },
             Ident(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
     }

@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(C::NT) void k_softemb_bwd(Shape s, const bf16raw* _
 //     also covers the stores of tile nt-1, which by then had a whole MFMA phase to drain.
 // PAIR: epi(tm, n, lo, hi) = columns [n, n+8) of this lane's row tm; else epi(tm, n, v) = [n, n+4).
 // ------------------------------------------------------------------------------------------------
-template <int KS, int PAIR, class Epi>     // PAIR: 0 = epi per accumulator tile, 1 = per pair of tiles, 2 = per 64-column tile (all of acc)
+template <int KS, int PAIR, bool DB = false, class Epi = void>     // DB: two LDS tile buffers, one barrier per tile; PAIR: 0 = epi per accumulator tile, 1 = per pair of tiles, 2 = per 64-column tile (all of acc)
 __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, const int (&mrow)[2], bool wave_any,
                                         int block_any, const bf16raw* __restrict__ Bt, int nt0, int nt1,
                                         unsigned char* Bs, Epi epi) {
@@ -1648,6 +1648,52 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
         const int rho = tn * 16 + (lane & 15);
         roff[tn] = rho * ROWB;
         rsw[tn] = (rho >> 1) & 7;
+    }
+    constexpr int TILEB = BN * ROWB;
+    if constexpr (DB) {
+        // two tile buffers: tile nt+1 is written (from the registers loaded one iteration earlier) while
+        // tile nt is multiplied; one workgroup barrier per tile
+        if (block_any) {
+            load_tile(nt0);
+#pragma unroll
+            for (int i = 0; i < SCH; ++i) *(u32x4*)&Bs[soff[i]] = st[i];
+            if (nt0 + 1 < nt1) load_tile(nt0 + 1);
+            __syncthreads();
+        }
+        for (int nt = nt0; nt < nt1; ++nt) {
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (block_any) {
+                const unsigned char* cur = Bs + ((nt - nt0) & 1) * TILEB;
+                if (nt + 1 < nt1) {
+                    unsigned char* nxt = Bs + ((nt + 1 - nt0) & 1) * TILEB;
+#pragma unroll
+                    for (int i = 0; i < SCH; ++i) *(u32x4*)&nxt[soff[i]] = st[i];
+                    if (nt + 2 < nt1) load_tile(nt + 2);
+                }
+                if (wave_any) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        bf16x8 bfr[4];
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            bfr[tn] = *(const bf16x8*)&cur[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+#pragma unroll
+                        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < 4; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+                    }
+                }
+            }
+            static_assert(!DB || PAIR == 2, "the double-buffered form is used with the per-tile epilogue");
+            epi(nt, acc);
+            if (block_any) __syncthreads();       // tile nt consumed by all, tile nt+1 written by all
+        }
+        return;
     }
     if (block_any) {
         load_tile(nt0);
@@ -2168,9 +2214,9 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* 
                                                        const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
                                                        float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
-    unsigned char* Bs = ip_lds;                                          // 64 * KS * 64 bytes
+    unsigned char* Bs = ip_lds;                                          // 2 x 64 * KS * 64 bytes (two W tile buffers)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char* scr = ip_lds + 64 * KS * 64 + wave * 8192;            // [32 rows][64 cols] fp32, 256-byte rows
+    unsigned char* scr = ip_lds + 2 * 64 * KS * 64 + wave * 8192;        // [32 rows][64 cols] fp32, 256-byte rows
     const int m0 = blockIdx.x * 256;
     const int ntiles = s.Ncat / 64;
     const int nt0 = blockIdx.y * nt_per;
@@ -2195,7 +2241,7 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* 
         srow[i] = (m < M && need[m] != 0) ? m : -1;
     }
     const int sc = lane & 15;
-    rs_gemm<KS, 2>(X, M, mrow, wave_any, block_any, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
+    rs_gemm<KS, 2, true>(X, M, mrow, wave_any, block_any, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
         if (!wave_any) return;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 113 /* 0.1.1 */
+#define SAD_VERSION 114 /* 0.1.1 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -152,6 +152,7 @@ enum sad_ws_field {
     SAD_WS_HX,       /* bf16 [2][2][B/16][Hp/8][16][8] hand-off image of h inside the persistent recurrence */
     SAD_WS_K1TILES,  /* int32: count + list of the 128-row tiles with a needed row (stream-K form of K1) */
     SAD_WS_K1SLABS,  /* fp32 [256][2][128*320] partial tiles of the stream-K form of K1, accumulator-fragment order */
+    SAD_WS_GA,       /* fp16 [T*B][2][Hp][4] activated gates (i, f, g, o per unit) when sad_uses_half_gates() */
     SAD_WS_NFIELDS
 };
 
@@ -166,6 +167,10 @@ size_t sad_packed_bytes(const sad_dims* d);
 /* Bytes of the per-call workspace (saved activations + backward scratch). 256-byte aligned base. */
 size_t sad_workspace_bytes(const sad_dims* d);
 int sad_workspace_field(const sad_dims* d, int field, size_t* offset, size_t* bytes);
+/* 1 when, for these dims on the current device, the recurrences run as persistent kernels and keep
+ * the activated LSTM gates as fp16 in SAD_WS_GA (G then holds the pre-activations of
+ * transfer/models.py:906's nn.LSTM input GEMM); 0 when the activated gates are fp32 in SAD_WS_G. */
+int sad_uses_half_gates(const sad_dims* d);
 
 /* state_dict fp32 -> packed image.  Replaces nothing in the reference (it consumes fp32 parameters
  * directly, transfer/models.py:770-827); call again whenever the parameters change. */

@@ -53,6 +53,29 @@ __device__ __forceinline__ u32x4 lp_pair16(u32x2 x, u32x2 y) {
 __device__ __forceinline__ void lp_store16_sc1(bf16raw* p, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
+// Activated gates of the persistent recurrences: fp16 [m][dir][unit][i, f, g, o] (SAD_WS_GA).  The
+// values lie in [-1, 1], so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
+// anyway); a lane's 4 units x 4 gates are 32 contiguous bytes.  Halves the gate stores of the forward
+// recurrence (47 us of its 305 at cfg3 were these stores) and the gate loads of the BPTT.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ga_store(unsigned short* p, const f32x4& gi, const f32x4& gf, const f32x4& gg, const f32x4& go) {
+    f16x8 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        lo[4 * e + 0] = (_Float16)gi[e]; lo[4 * e + 1] = (_Float16)gf[e]; lo[4 * e + 2] = (_Float16)gg[e]; lo[4 * e + 3] = (_Float16)go[e];
+        hi[4 * e + 0] = (_Float16)gi[2 + e]; hi[4 * e + 1] = (_Float16)gf[2 + e]; hi[4 * e + 2] = (_Float16)gg[2 + e]; hi[4 * e + 3] = (_Float16)go[2 + e];
+    }
+    *(f16x8*)p = lo;
+    *(f16x8*)(p + 8) = hi;
+}
+__device__ __forceinline__ void ga_load(const unsigned short* p, f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go) {
+    const f16x8 lo = *(const f16x8*)p, hi = *(const f16x8*)(p + 8);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        gi[e] = (float)lo[4 * e + 0]; gf[e] = (float)lo[4 * e + 1]; gg[e] = (float)lo[4 * e + 2]; go[e] = (float)lo[4 * e + 3];
+        gi[2 + e] = (float)hi[4 * e + 0]; gf[2 + e] = (float)hi[4 * e + 1]; gg[2 + e] = (float)hi[4 * e + 2]; go[2 + e] = (float)hi[4 * e + 3];
+    }
+}
 __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
 }
@@ -322,7 +345,7 @@ __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int* __restrict__ lens,
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
-                                                          unsigned* sync) {
+                                                          unsigned short* __restrict__ GA, unsigned* sync) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
     bf16raw* Wl = (bf16raw*)lp_lds;                          // [64][Hp], chunk-swizzled
@@ -508,11 +531,15 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
             if (!act[tm]) continue;
-            float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
-            *(f32x4*)(g + 0) = gi[tm];
-            *(f32x4*)(g + 16) = gf[tm];
-            *(f32x4*)(g + 32) = gg[tm];
-            *(f32x4*)(g + 48) = go[tm];
+            if (GA != nullptr) {
+                ga_store(GA + ((((long long)t * B + brow[tm]) * 2 + dir) * Hp + j) * 4, gi[tm], gf[tm], gg[tm], go[tm]);
+            } else {
+                float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
+                *(f32x4*)(g + 0) = gi[tm];
+                *(f32x4*)(g + 16) = gf[tm];
+                *(f32x4*)(g + 32) = gg[tm];
+                *(f32x4*)(g + 48) = go[tm];
+            }
             *(f32x4*)&Cs[(((long long)t * B + brow[tm]) * 2 + dir) * Hp + j] = creg[tm];
         }
         LF_PROF_T(6)
@@ -569,7 +596,7 @@ __host__ __device__ inline size_t lstm_bwd_xchg_bytes(int B, int Gp) {
 __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __restrict__ lens,
                                                          const bf16raw* __restrict__ whhT, const float* __restrict__ G,
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
-                                                         bf16raw* DZ, bf16raw* DZX, unsigned* sync) {
+                                                         bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
     bf16raw* Wl = (bf16raw*)lp_lds;                                  // [32][Gp], chunk-swizzled
@@ -649,11 +676,15 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
             egi[tn] = egf[tn] = egg[tn] = ego[tn] = ec[tn] = ecp[tn] = edhf[tn] = z;
             if (!act) continue;
-            const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + pcu[tn];
-            egi[tn] = *(const f32x4*)(g + 0);
-            egf[tn] = *(const f32x4*)(g + 16);
-            egg[tn] = *(const f32x4*)(g + 32);
-            ego[tn] = *(const f32x4*)(g + 48);
+            if (GA != nullptr) {
+                ga_load(GA + ((((long long)t * B + b) * 2 + dir) * Hp + ju[tn]) * 4, egi[tn], egf[tn], egg[tn], ego[tn]);
+            } else {
+                const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + pcu[tn];
+                egi[tn] = *(const f32x4*)(g + 0);
+                egf[tn] = *(const f32x4*)(g + 16);
+                egg[tn] = *(const f32x4*)(g + 32);
+                ego[tn] = *(const f32x4*)(g + 48);
+            }
             ec[tn] = *(const f32x4*)&Cs[(((long long)t * B + b) * 2 + dir) * Hp + ju[tn]];
             if (tpf >= 0 && tpf < T && len > tpf) ecp[tn] = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + ju[tn]];
             const bool last = dir ? (t == 0) : (t == len - 1);

@@ -95,6 +95,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
     w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
     w.bytes[SAD_WS_HX] = lstm_fwd_xchg_bytes(s.B, s.Hp);
+    w.bytes[SAD_WS_GA] = M * 2 * s.Hp * 4 * 2;
     const bool k1_sk = s.Ep == 320;                          // the stream-K form of K1 (run_softemb_fwd) and of K2a'+K3'
     w.bytes[SAD_WS_K1TILES] = k1_sk ? ((size_t)ceil_div(s.M, 128) + 4) * 4 : 0;
     w.bytes[SAD_WS_K1SLABS] = k1_sk ? (size_t)K1_MAX_WGS * 2 * K1_SLAB_FLOATS * 4 : 0;
@@ -353,6 +354,14 @@ bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     *grid = 2 * ceil_div(s.B, LB_BM) * (s.Hp / LB_BN);
     return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid);
 }
+// fp16 activated gates (SAD_WS_GA) are written by the half-width forward recurrence and read by the
+// persistent BPTT: used when both run (same decision in sad_forward and sad_backward; SAD_HALF_GATES=0
+// keeps fp32 gates in G).
+bool half_gates(const Shape& s) {
+    static const bool on = getenv("SAD_HALF_GATES") == nullptr || atoi(getenv("SAD_HALF_GATES")) != 0;
+    int g1 = 0, g2 = 0;
+    return on && lstm_persist2_fits(s, &g1) && lstm_bwd_persist_fits(s, &g2);
+}
 
 // sad_pack_weights collects its jobs here and launches them together (k_pack_all)
 struct PackBatch {
@@ -391,6 +400,12 @@ extern "C" {
 
 int sad_version(void) { return SAD_VERSION; }
 const char* sad_last_error(void) { return g_err; }
+
+int sad_uses_half_gates(const sad_dims* d) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    return half_gates(s) ? 1 : 0;
+}
 
 int sad_padded_dims(const sad_dims* d, int32_t out[5]) {
     Shape s;
@@ -608,7 +623,8 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
     (void)hipMemsetAsync(sync, 0, wl.bytes[SAD_WS_SYNC], st);   // counters + timeout word, every call
     if (lstm_persist2_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), st, s, lens,
-                           at<bf16raw>(packed, pl.whh), G, Cs, Hs, at<bf16raw>(ws, wl.off[SAD_WS_HX]), sync);
+                           at<bf16raw>(packed, pl.whh), G, Cs, Hs, at<bf16raw>(ws, wl.off[SAD_WS_HX]),
+                           half_gates(s) ? at<unsigned short>(ws, wl.off[SAD_WS_GA]) : (unsigned short*)nullptr, sync);
     } else if (lstm_persist_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_fwd_persist, dim3(pgrid), dim3(512), lstm_persist_lds_bytes(s.Hp), st, s, lens,
                            at<bf16raw>(packed, pl.whh), G, Cs, Hs, sync);
@@ -718,7 +734,8 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
         // counters only: the timeout words behind them keep what the forward left
         (void)hipMemsetAsync(sync, 0, (size_t)2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH * 4, st);
         hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), st, s, lens,
-                           at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, at<bf16raw>(ws, wl.off[SAD_WS_DZX]), sync);
+                           at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, at<bf16raw>(ws, wl.off[SAD_WS_DZX]),
+                           half_gates(s) ? at<unsigned short>(ws, wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr, sync);
     } else {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;

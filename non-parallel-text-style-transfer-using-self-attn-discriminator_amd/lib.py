@@ -15,12 +15,12 @@ LIB_PATH = os.environ.get("SAD_LIB") or os.path.join(_HERE, "_native", "libsad.s
 SRC_IDS, SRC_F32, SRC_BF16 = 0, 1, 2
 
 WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", "DX", "DU", "DQ",
-             "DHFIN", "DC", "ACCF", "DL", "DWA", "DSSUM", "ROWS", "NROWS", "SYNC", "DZX", "HX", "K1TILES", "K1SLABS")
+             "DHFIN", "DC", "ACCF", "DL", "DWA", "DSSUM", "ROWS", "NROWS", "SYNC", "DZX", "HX", "K1TILES", "K1SLABS", "GA")
 
 # every symbol include/sad.h declares (tests/test_cabi.py checks the .so exports all of them)
 EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",
            "sad_workspace_bytes", "sad_workspace_field", "sad_pack_weights", "sad_forward",
-           "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd")
+           "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd", "sad_uses_half_gates")
 
 
 class SadDims(ctypes.Structure):
@@ -98,6 +98,8 @@ def load():
     lib.sad_backward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadBwdArgs), c_void_p, c_void_p]
     lib.sad_param_grads_accumulate.argtypes = [POINTER(SadDims), POINTER(SadParamGrads), c_void_p, c_int32, c_int64,
                                                c_int64, c_int32, c_void_p, c_void_p]
+    lib.sad_uses_half_gates.argtypes = [POINTER(SadDims)]
+    lib.sad_uses_half_gates.restype = c_int
     lib.sad_prep.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]
     lib.sad_softemb_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]
     lib.sad_softemb_bwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]

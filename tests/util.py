@@ -113,12 +113,19 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
         pd = lib.padded_dims(ws.d)
         Ep, Hp, Gp, Ncat = pd["Ep"], pd["Hp"], pd["Gp"], pd["Ncat"]
         f = lambda name, dt: ws.view(name, dt)
+        import ctypes
+        Gact = f("G", torch.float32).cpu().numpy().reshape(T, B, 2 * Gp + 64)[:, :, :2 * Gp].reshape(T, B, 2, Gp)
+        if lib.load().sad_uses_half_gates(ctypes.byref(ws.d)) == 1:
+            # persistent recurrences: activated gates are fp16 [T,B,2,Hp,(i,f,g,o)]; bring them to the
+            # permuted-column layout of G: pc = (unit/16)*64 + gate*16 + unit%16
+            ga = f("GA", torch.float16).float().cpu().numpy().reshape(T, B, 2, Hp, 4)
+            Gact = ga.reshape(T, B, 2, Hp // 16, 16, 4).transpose(0, 1, 2, 3, 5, 4).reshape(T, B, 2, Gp).copy()
         out["ws"] = dict(
             pd=pd,
             LENS=f("LENS", torch.int32).cpu().numpy(),
             NEED=f("NEED", torch.uint8).cpu().numpy().reshape(T, B),
             X=f("X", torch.bfloat16).float().cpu().numpy().reshape(T, B, Ep),
-            G=f("G", torch.float32).cpu().numpy().reshape(T, B, 2 * Gp + 64)[:, :, :2 * Gp].reshape(T, B, 2, Gp),
+            G=Gact,
             CS=f("CS", torch.float32).cpu().numpy().reshape(T, B, 2, Hp),
             HS=f("HS", torch.bfloat16).float().cpu().numpy().reshape(T, B, 2, Hp),
             KK=f("KK", torch.float32).cpu().numpy().reshape(T, B, Hp),

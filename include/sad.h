@@ -152,7 +152,8 @@ enum sad_ws_field {
     SAD_WS_HX,       /* bf16 [2][2][B/16][Hp/8][16][8] hand-off image of h inside the persistent recurrence */
     SAD_WS_K1TILES,  /* int32: count + list of the 128-row tiles with a needed row (stream-K form of K1) */
     SAD_WS_K1SLABS,  /* fp32 [256][2][128*320] partial tiles of the stream-K form of K1, accumulator-fragment order */
-    SAD_WS_GA,       /* fp16 [T*B][2][Hp][4] activated gates (i, f, g, o per unit) when sad_uses_half_gates() */
+    SAD_WS_GA,       /* fp16 [T][2][B/16][Hp/4][16 sentences][4 units][i, f, g, o] activated gates when
+                        sad_uses_half_gates() */
     SAD_WS_NFIELDS
 };
 

@@ -53,11 +53,20 @@ __device__ __forceinline__ u32x4 lp_pair16(u32x2 x, u32x2 y) {
 __device__ __forceinline__ void lp_store16_sc1(bf16raw* p, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
-// Activated gates of the persistent recurrences: fp16 [m][dir][unit][i, f, g, o] (SAD_WS_GA).  The
+// Activated gates of the persistent recurrences: fp16 records of [unit][i, f, g, o] (SAD_WS_GA).  The
 // values lie in [-1, 1], so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
 // anyway); a lane's 4 units x 4 gates are 32 contiguous bytes.  Halves the gate stores of the forward
 // recurrence (47 us of its 305 at cfg3 were these stores) and the gate loads of the BPTT.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Record (4 units x 4 gates, 32 bytes) of sentence b, unit quad j/4 at step t: [t][dir][16-sentence
+// block][quad][16 sentences][16 halves] -- the lane mapping of both recurrences is lane & 15 = sentence,
+// lane >> 4 = quad, so a wave instruction covers 2 KB of contiguous bytes (row-major records gave 16
+// cache lines per quarter wave, the fragment-shaped access the hand-off images avoid).
+__host__ __device__ inline size_t ga_bytes(int T, int B, int Hp) { return (size_t)T * 2 * ((B + 15) / 16 * 16) * Hp * 4 * 2; }
+__device__ __forceinline__ long long ga_index(int t, int dir, int b, int j, int B, int Hp) {
+    const int sblocks = (B + 15) >> 4;
+    return (((((long long)t * 2 + dir) * sblocks + (b >> 4)) * (Hp >> 2) + (j >> 2)) * 16 + (b & 15)) * 16;
+}
 __device__ __forceinline__ void ga_store(unsigned short* p, const f32x4& gi, const f32x4& gf, const f32x4& gg, const f32x4& go) {
     f16x8 lo, hi;
 #pragma unroll
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         for (int tm = 0; tm < 2; ++tm) {
             if (!act[tm]) continue;
             if (GA != nullptr) {
-                ga_store(GA + ((((long long)t * B + brow[tm]) * 2 + dir) * Hp + j) * 4, gi[tm], gf[tm], gg[tm], go[tm]);
+                ga_store(GA + ga_index(t, dir, brow[tm], j, B, Hp), gi[tm], gf[tm], gg[tm], go[tm]);
             } else {
                 float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
                 *(f32x4*)(g + 0) = gi[tm];
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
             egi[tn] = egf[tn] = egg[tn] = ego[tn] = ec[tn] = ecp[tn] = edhf[tn] = z;
             if (!act) continue;
             if (GA != nullptr) {
-                ga_load(GA + ((((long long)t * B + b) * 2 + dir) * Hp + ju[tn]) * 4, egi[tn], egf[tn], egg[tn], ego[tn]);
+                ga_load(GA + ga_index(t, dir, b, ju[tn], B, Hp), egi[tn], egf[tn], egg[tn], ego[tn]);
             } else {
                 const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + pcu[tn];
                 egi[tn] = *(const f32x4*)(g + 0);

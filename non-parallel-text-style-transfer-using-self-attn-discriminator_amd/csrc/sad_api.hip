@@ -95,7 +95,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
     w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
     w.bytes[SAD_WS_HX] = lstm_fwd_xchg_bytes(s.B, s.Hp);
-    w.bytes[SAD_WS_GA] = M * 2 * s.Hp * 4 * 2;
+    w.bytes[SAD_WS_GA] = ga_bytes(s.T, s.B, s.Hp);
     const bool k1_sk = s.Ep == 320;                          // the stream-K form of K1 (run_softemb_fwd) and of K2a'+K3'
     w.bytes[SAD_WS_K1TILES] = k1_sk ? ((size_t)ceil_div(s.M, 128) + 4) * 4 : 0;
     w.bytes[SAD_WS_K1SLABS] = k1_sk ? (size_t)K1_MAX_WGS * 2 * K1_SLAB_FLOATS * 4 : 0;

@@ -118,7 +118,9 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
         if lib.load().sad_uses_half_gates(ctypes.byref(ws.d)) == 1:
             # persistent recurrences: activated gates are fp16 [T,B,2,Hp,(i,f,g,o)]; bring them to the
             # permuted-column layout of G: pc = (unit/16)*64 + gate*16 + unit%16
-            ga = f("GA", torch.float16).float().cpu().numpy().reshape(T, B, 2, Hp, 4)
+            Bp = (B + 15) // 16 * 16       # records: [T][2][B/16][Hp/4][16 sentences][4 units][4 gates]
+            ga = f("GA", torch.float16).float().cpu().numpy().reshape(T, 2, Bp // 16, Hp // 4, 16, 4, 4)
+            ga = ga.transpose(0, 2, 4, 1, 3, 5, 6).reshape(T, Bp, 2, Hp, 4)[:, :B]
             Gact = ga.reshape(T, B, 2, Hp // 16, 16, 4).transpose(0, 1, 2, 3, 5, 4).reshape(T, B, 2, Gp).copy()
         out["ws"] = dict(
             pd=pd,

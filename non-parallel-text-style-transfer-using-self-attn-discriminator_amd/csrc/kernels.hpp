@@ -23,7 +23,12 @@ enum { SRC_IDS = 0, SRC_F32 = 1, SRC_BF16 = 2 };
 // (transfer/models.py:865-867), derive the per-token need bits.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_prep(Shape s, const int* __restrict__ lens_in, unsigned char* mask, long long msb, long long mst,
-                       int guard, unsigned char* __restrict__ need, int* __restrict__ lens) {
+                       int guard, unsigned char* __restrict__ need, int* __restrict__ lens, unsigned* __restrict__ sync,
+                       int sync_words) {
+    // hand-off counters + timeout words of the persistent recurrence start from zero every call (a
+    // separate memset node cost 4.5 us)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < sync_words; i += blockDim.x) sync[i] = 0u;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= s.B) return;
     int len = lens_in[b];
@@ -1274,8 +1279,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
                                                  float dloss_scale, const float* __restrict__ dweights,
                                                  bf16raw* __restrict__ DZ, float* __restrict__ DU,
                                                  float* __restrict__ DL, float* __restrict__ DWA,
-                                                 float* __restrict__ DSSUM) {
+                                                 float* __restrict__ DSSUM, unsigned* __restrict__ sync, int sync_words) {
     __shared__ float dl[ATT_MAX_L];
+    // hand-off counters of the persistent BPTT start from zero (the timeout words behind them keep
+    // what the forward left)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < sync_words; i += 256) sync[i] = 0u;
     __shared__ __attribute__((aligned(16))) float dux[4][NV * 256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Hp = s.Hp, B = s.B, T = s.T, L = s.L;

@@ -22,7 +22,8 @@
 //             workgroup barrier; EVERY load of h is an 8-byte agent-scope (sc1) load to registers.
 // No other load in the kernel touches bytes another workgroup writes during the launch (G tiles and
 // Cs are private to the workgroup; W_hh and lens are read-only).
-// Counters are zeroed by a hipMemsetAsync in front of every launch.  All workgroups must be
+// Counters are zeroed in front of every launch by a kernel of the same call that runs earlier on the
+// stream (k_prep in the forward, k_attn_bwd in the backward: a separate memset node cost 4.5 us).  All workgroups must be
 // co-resident: the host checks the grid against the occupancy query and otherwise runs the
 // one-launch-per-step kernels.  Spins are bounded: a timeout sets the error word and ends waiting.
 #pragma once

@@ -309,7 +309,8 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
 int run_prep(const Shape& s, const WsLayout& wl, void* ws, const int32_t* lengths, uint8_t* mask, long long msb,
              long long mst, int guard, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3(ceil_div(s.B, 64)), dim3(64), 0, st, s, lengths, mask, msb, mst, guard,
-                       at<unsigned char>(ws, wl.off[SAD_WS_NEED]), at<int>(ws, wl.off[SAD_WS_LENS]));
+                       at<unsigned char>(ws, wl.off[SAD_WS_NEED]), at<int>(ws, wl.off[SAD_WS_LENS]),
+                       at<unsigned>(ws, wl.off[SAD_WS_SYNC]), (int)(wl.bytes[SAD_WS_SYNC] / 4));
     SAD_CHECK_LAUNCH("k_prep");
     return 0;
 }
@@ -620,7 +621,7 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
     // grid is co-resident, else T dependent launches (both directions per launch).
     int pgrid = 0;
     unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
-    (void)hipMemsetAsync(sync, 0, wl.bytes[SAD_WS_SYNC], st);   // counters + timeout word, every call
+    // (counters + timeout words were zeroed by k_prep of this call)
     if (lstm_persist2_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), st, s, lens,
                            at<bf16raw>(packed, pl.whh), G, Cs, Hs, at<bf16raw>(ws, wl.off[SAD_WS_HX]),
@@ -708,7 +709,8 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     hipLaunchKernelGGL((k_attn_bwd<NV>), dim3(s.B), dim3(256), 0, st, s, Kk, U, wa, wo, a->weights, CTX, a->logits, \
                        lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU,                              \
                        at<float>(ws, wl.off[SAD_WS_DL]), at<float>(ws, wl.off[SAD_WS_DWA]),                         \
-                       at<float>(ws, wl.off[SAD_WS_DSSUM]))
+                       at<float>(ws, wl.off[SAD_WS_DSSUM]), at<unsigned>(ws, wl.off[SAD_WS_SYNC]),                  \
+                       2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH)
         if (s.Hp <= 256) SAD_ATT_BWD(1);
         else if (s.Hp <= 512) SAD_ATT_BWD(2);
         else if (s.Hp <= 1024) SAD_ATT_BWD(4);
@@ -732,7 +734,7 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     if (lstm_bwd_persist_fits(s, &pgrid)) {
         unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
         // counters only: the timeout words behind them keep what the forward left
-        (void)hipMemsetAsync(sync, 0, (size_t)2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH * 4, st);
+        // (zeroed by k_attn_bwd of this call)
         hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), st, s, lens,
                            at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, at<bf16raw>(ws, wl.off[SAD_WS_DZX]),
                            half_gates(s) ? at<unsigned short>(ws, wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr, sync);

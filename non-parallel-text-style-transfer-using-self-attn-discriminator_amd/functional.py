@@ -385,6 +385,31 @@ def _se_packed(weight):
     return pw
 
 
+_se_ws = {}
+
+
+def _se_workspace(B, T, V, E, dev):
+    """One workspace per shape, shared by all calls (a decoder runs this once per time step and keeps
+    every call alive until the backward): it only carries the need bits (every row needed, written
+    once by sad_prep), X (copied out by forward) and DX (filled by backward right before use), so
+    calls on one stream can share it."""
+    key = (B, T, V, E, str(dev))
+    hit = _se_ws.get(key)
+    if hit is not None:
+        return hit
+    d = _lib.dims(B, T, V, E, _SE_H, _SE_L)
+    ws = Workspace(d, dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    mask = torch.zeros((B, T), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().sad_prep(ctypes.byref(d), _ptr(lens), _ptr(mask), mask.stride(0), mask.stride(1), 0,
+                                        _ptr(ws.buf), _stream_ptr()), "sad_prep")
+    if len(_se_ws) > 4:
+        _se_ws.clear()
+    _se_ws[key] = (d, ws)
+    return d, ws
+
+
 class _SoftEmbedding(torch.autograd.Function):
     @staticmethod
     def forward(ctx, S, weight):
@@ -408,15 +433,10 @@ class _SoftEmbedding(torch.autograd.Function):
         E = weight.shape[1]
         dev = S.device
         pw = _se_packed(weight)
-        d = _lib.dims(B, T, V, E, _SE_H, _SE_L)
-        ws = Workspace(d, dev)
+        d, ws = _se_workspace(B, T, V, E, dev)
         kind = _lib.SRC_F32 if S.dtype == torch.float32 else _lib.SRC_BF16
-        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
-        mask = torch.zeros((B, T), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             lib = _lib.load()
-            _lib.check(lib.sad_prep(ctypes.byref(d), _ptr(lens), _ptr(mask), mask.stride(0), mask.stride(1), 0,
-                                    _ptr(ws.buf), _stream_ptr()), "sad_prep")
             _lib.check(lib.sad_softemb_fwd(ctypes.byref(d), _ptr(pw.buf), _ptr(Sv), kind, Sv.stride(1), Sv.stride(0),
                                            _ptr(ws.buf), _stream_ptr()), "sad_softemb_fwd")
         Ep = _lib.padded_dims(d)["Ep"]

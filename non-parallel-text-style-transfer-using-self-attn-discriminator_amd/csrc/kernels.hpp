@@ -2215,7 +2215,7 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs(Shape s, const bf16raw* _
 
 // K2a + K3, A-stationary, with the output tile turned through a wave-private LDS scratch: the
 // accumulator layout gives 16-byte pieces of 16 different rows per quarter wave; after the turn a
-// store instruction writes full 128-byte row segments of 8 rows.  No extra workgroup barrier: a
+// store instruction writes full 256-byte row segments of 4 rows.  No extra workgroup barrier: a
 // wave's LDS operations execute in program order.
 template <int KS>
 __global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* __restrict__ X,

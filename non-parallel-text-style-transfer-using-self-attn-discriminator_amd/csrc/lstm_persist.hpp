@@ -15,11 +15,11 @@
 //
 // Hand-off of h between workgroups INSIDE the launch follows cdna_hip_programming.md Guideline 16 /
 // MI355X_MICROARCH.md "Valid forms" row 1, in the form that needs no cache-wide fence:
-//   producer: every h store is an 8-byte agent-scope (sc1, write-through) store; every storing wave
+//   producer: every h store is a 16-byte agent-scope (sc1, write-through) store; every storing wave
 //             drains (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane adds 1 to the group counter
 //             (agent-scope atomic);
 //   consumer: ONE lane polls the counter (relaxed agent-scope = sc1 load) with s_sleep, bounded;
-//             workgroup barrier; EVERY load of h is an 8-byte agent-scope (sc1) load to registers.
+//             workgroup barrier; EVERY load of h is a 16-byte agent-scope (sc1) buffer load to registers.
 // No other load in the kernel touches bytes another workgroup writes during the launch (G tiles and
 // Cs are private to the workgroup; W_hh and lens are read-only).
 // Counters are zeroed in front of every launch by a kernel of the same call that runs earlier on the

@@ -654,16 +654,6 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         pcu[tn] = (ju[tn] >> 4) * 64 + (ju[tn] & 15);
         dcreg[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // dZ rows of padded steps (t >= len) are exact zeros: later kernels read every row of DZ.
-    if (b < B) {
-        for (int t = len; t < T; ++t) {
-            bf16raw* zrow = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) *(u32x2*)&zrow[pcu[tn] + g * 16] = u32x2{0u, 0u};
-        }
-    }
     const int nsg = Gp / 128;                                // fragment sets of 4 x 32 k
     // hand-off image of dZ (see lstm_bwd_xchg_bytes): [parity][dir][16-sentence block][8-column chunk][16][8]
     const int sblocks = rtiles * (LB_BM / 16);
@@ -821,6 +811,18 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         }
         LB_PROF_T(6)
         LB_PROF_END
+    }
+    // dZ rows of padded steps (t >= len) are exact zeros: later kernels read every row of DZ.  Done
+    // after the recurrence: tiles of short sentences have the most of these rows and finish their
+    // steps first, so the stores no longer sit in front of the first hand-offs of the long tiles.
+    if (b < B) {
+        for (int t = len; t < T; ++t) {
+            bf16raw* zrow = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(u32x2*)&zrow[pcu[tn] + g * 16] = u32x2{0u, 0u};
+        }
     }
     LB_PROF_OUT
 }

@@ -78,8 +78,8 @@ __device__ __forceinline__ void ga_store(unsigned short* p, const f32x4& gi, con
     *(f16x8*)p = lo;
     *(f16x8*)(p + 8) = hi;
 }
-__device__ __forceinline__ void ga_load(const unsigned short* p, f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go) {
-    const f16x8 lo = *(const f16x8*)p, hi = *(const f16x8*)(p + 8);
+__device__ __forceinline__ void ga_unpack(const u32x4& rlo, const u32x4& rhi, f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go) {
+    const f16x8 lo = __builtin_bit_cast(f16x8, rlo), hi = __builtin_bit_cast(f16x8, rhi);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         gi[e] = (float)lo[4 * e + 0]; gf[e] = (float)lo[4 * e + 1]; gg[e] = (float)lo[4 * e + 2]; go[e] = (float)lo[4 * e + 3];
@@ -578,6 +578,9 @@ namespace sad {
 #ifndef SAD_LB_NS
 #define SAD_LB_NS 2
 #endif
+#ifndef SAD_LB_ABL
+#define SAD_LB_ABL 0      // timing-only ablation (debug builds): 1 no row-major dZ copy
+#endif
 constexpr int LB_BM = 128, LB_BN = 32, LB_SG_MAX = 16, LB_NS = SAD_LB_NS;       // Gp <= 128 * LB_SG_MAX
 
 __host__ __device__ inline size_t lstm_bwd_persist_lds_bytes(int Gp) { return (size_t)LB_BN * Gp * 2 + 16; }
@@ -591,12 +594,14 @@ __host__ __device__ inline size_t lstm_bwd_xchg_bytes(int B, int Gp) {
 
 #ifdef SAD_LB_PROF
 // debug build only: phase timers (100 MHz wall clock) of one workgroup -> the free words after the timeout words
-#define LB_PROF_DECL unsigned long long pt[7] = {0,0,0,0,0,0,0}, pa[7] = {0,0,0,0,0,0,0}; unsigned psteps = 0;
+#define LB_PROF_ENTRY const unsigned long long p_entry = wall_clock64();
+#define LB_PROF_DECL unsigned long long pt[7] = {0,0,0,0,0,0,0}, pa[7] = {0,0,0,0,0,0,0}, p_last6 = 0, p_gap = 0; unsigned psteps = 0; const unsigned long long p_loop = wall_clock64();
 #define LB_PROF_T(i) pt[i] = wall_clock64();
 #define LB_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0]), "v"(acc[1][0])); }
-#define LB_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; }
-#define LB_PROF_OUT if (tid == 0 && group == SAD_LB_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)groups * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; }
+#define LB_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; if (p_last6) p_gap += pt[0] - p_last6; } p_last6 = pt[6];
+#define LB_PROF_OUT if (tid == 0 && group == SAD_LB_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)groups * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; o[7] = p_loop - p_entry; o[8] = wall_clock64() - p_entry; o[9] = p_gap; }
 #else
+#define LB_PROF_ENTRY
 #define LB_PROF_DECL
 #define LB_PROF_T(i)
 #define LB_PROF_ACC
@@ -609,6 +614,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                                                          bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
+    LB_PROF_ENTRY
     bf16raw* Wl = (bf16raw*)lp_lds;                                  // [32][Gp], chunk-swizzled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctiles = Hp / LB_BN, rtiles = (B + LB_BM - 1) / LB_BM, groups = rtiles * 2;
@@ -661,6 +667,9 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     const unsigned xrow = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave) * (Gp / 8) * 128 + (lane & 15) * 8);
     unsigned done = 0;
     bool dead = false;
+    int t_carry = -1;                                        // step whose c is held in eccarry (per lane)
+    f32x4 eccarry[2];
+    eccarry[0] = eccarry[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     LB_PROF_DECL
 
     for (int step = 0; step < T; ++step) {
@@ -671,13 +680,19 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         const bool act = len > t;
         // epilogue operands: private to the workgroup, independent of the hand-off -> issued first
         f32x4 egi[2], egf[2], egg[2], ego[2], ec[2], ecp[2], edhf[2];
+        u32x4 graw[2][2];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
             egi[tn] = egf[tn] = egg[tn] = ego[tn] = ec[tn] = ecp[tn] = edhf[tn] = z;
+            graw[tn][0] = graw[tn][1] = u32x4{0u, 0u, 0u, 0u};
             if (!act) continue;
             if (GA != nullptr) {
-                ga_load(GA + ga_index(t, dir, b, ju[tn], B, Hp), egi[tn], egf[tn], egg[tn], ego[tn]);
+                // raw fp16 records now, converted after the K loop: converting here would wait for the
+                // loads in front of the poll (measured: 2 us per step)
+                const unsigned short* ga = GA + ga_index(t, dir, b, ju[tn], B, Hp);
+                graw[tn][0] = *(const u32x4*)ga;
+                graw[tn][1] = *(const u32x4*)(ga + 8);
             } else {
                 const float* g = G + ((long long)t * B + b) * s.Gld + dir * Gp + pcu[tn];
                 egi[tn] = *(const f32x4*)(g + 0);
@@ -685,11 +700,15 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                 egg[tn] = *(const f32x4*)(g + 32);
                 ego[tn] = *(const f32x4*)(g + 48);
             }
-            ec[tn] = *(const f32x4*)&Cs[(((long long)t * B + b) * 2 + dir) * Hp + ju[tn]];
+            // c_t was this lane's c_prev of the step before (t == the tpf of that step): carried in registers
+            if (t_carry == t) ec[tn] = eccarry[tn];
+            else ec[tn] = *(const f32x4*)&Cs[(((long long)t * B + b) * 2 + dir) * Hp + ju[tn]];
             if (tpf >= 0 && tpf < T && len > tpf) ecp[tn] = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + ju[tn]];
+            eccarry[tn] = ecp[tn];
             const bool last = dir ? (t == 0) : (t == len - 1);
             if (last) edhf[tn] = *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + ju[tn]];
         }
+        t_carry = (act && tpf >= 0 && tpf < T && len > tpf) ? tpf : -1;
         f32x4 acc[2];
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         LB_PROF_T(0)
@@ -757,6 +776,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         if (act) {
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
+                if (GA != nullptr) ga_unpack(graw[tn][0], graw[tn][1], egi[tn], egf[tn], egg[tn], ego[tn]);
                 const f32x4 dh = acc[tn] + edhf[tn];
                 const f32x4 dcin = (tn_ >= 0 && tn_ < T && len > tn_) ? dcreg[tn] : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 zi, zf, zg, zo, dcn;
@@ -799,7 +819,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
         ++done;
-        if (act) {
+        if (act && SAD_LB_ABL != 1) {
             // row-major copy for the kernels after the recurrence: not part of the hand-off, plain stores
             bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
             const int q = lane >> 4;

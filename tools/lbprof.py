@@ -20,10 +20,12 @@ for it in range(3):
         loss.mean().backward()
     torch.cuda.synchronize()
 ws = Fn._Discriminator.last_workspace
-v = ws.view("SYNC", torch.int64)[-12:-5].cpu().tolist()
+v = ws.view("SYNC", torch.int64)[-12:-2].cpu().tolist()
 n = max(1, v[6])
 names = ["poll", "barrier", "operand loads + K loop", "epilogue + store issue", "store drain", "barrier + signal (+ private stores, fwd)"]
 print("steps", v[6], " us/step:")
 for nm, x in zip(names, v[:6]):
     print("  %-26s %7.2f" % (nm, x / n / 100.0))
 print("  total %.2f" % (sum(v[:6]) / n / 100.0))
+if not os.environ.get("LB_FWD"):
+    print("  prologue %.2f us, whole kernel (this workgroup) %.2f us, between steps %.2f us/step" % (v[7] / 100.0, v[8] / 100.0, v[9] / n / 100.0))

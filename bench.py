@@ -7,15 +7,24 @@
 One "step" = one pass of the hot path over one batch already resident in HBM: forward on soft
 tokens (K1 soft-embedding GEMM, K2 BiLSTM, K3 keys, K4 bridge, K5 attention/head/CE vs labels) +
 backward to d(soft tokens) with frozen parameters — what reference transfer/models.py:1185-1212 +
-transfer/trainers.py:376 run per training step.  Weak scaling: every rank owns a full per-GPU batch
-(independent sentences; no data-path collective in frozen mode, DESIGN.md "Multi-GPU").
+transfer/trainers.py:376 run per training step.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
-timed live with events on the launch stream) and `cpu_baseline` (stock-torch port of the reference
-op sequence from oracle/torch_ref.py on the host cores; N=1 only).
+  --workload cfg3|yelp64|stress   BASELINE.json configs[2]/[3] (default), configs[1], configs[4] per-GPU slice
+  --scaling weak|strong           weak: every rank owns a full per-GPU batch (default);
+                                  strong: the SAME global batch split over the ranks (BASELINE configs[3]:
+                                  1024 sentences -> 512 / 256 / 128 per GPU)
+  --api fused|module              fused: functional.discriminator_loss (device lengths, CE inside the
+                                  attention kernel); module: the drop-in SelfAttnRNNClassifier.forward(soft=True)
+                                  with CPU int16 lengths + F.cross_entropy(1 - lab), as the transfer loop calls it
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (the longest kernel
+of the step), `kernels` (every kernel class of SURVEY.md §8 d3, each timed in isolation through its
+C-ABI stage entry point with events on the launch stream) and `cpu_baseline` (stock-torch port of the
+reference op sequence from oracle/torch_ref.py on the host cores; N=1 only).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -41,12 +50,24 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_PEAK_TFS = 2500.0      # dense bf16 MFMA (spec)
 
 
-def make_inputs(w, seed, dev):
+def source_id():
+    """Hash of the kernel sources + header: ties committed PMC counter files to the build they were
+    taken from (bench refuses a traffic file from another build)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "non-parallel-text-style-transfer-using-self-attn-discriminator_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hpp", ".hip")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "sad.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def make_inputs(w, seed, dev, yelp_lengths=False):
     """Synthetic batch of SURVEY.md §8 d2, generated on the device (seeded): dense softmax soft
     tokens, one-hot [sos] at t=0 and one-hot [pad] for t >= len; sorted-descending lengths."""
     from sad_amd import synth
     B, T, V = w["B"], w["T"], w["V"]
-    lengths = synth.make_lengths(B, T, seed=seed)
+    lengths = synth.yelp_dev_lengths(B, T, seed=seed) if yelp_lengths else synth.make_lengths(B, T, seed=seed)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     dt = torch.bfloat16 if w["s_dtype"] == "bf16" else torch.float32
@@ -65,13 +86,15 @@ def make_inputs(w, seed, dev):
     return S, lengths, ln.to(torch.int32), mask, labels
 
 
-def time_kernel(fn, iters=10, warm=2):
+def time_launches(fn, iters=10, warm=2):
+    """Average duration of back-to-back launches, events on torch's current stream == the stream
+    libsad launches on."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()     # events on torch's current stream == the stream libsad launches on
+    e0.record()
     for _ in range(iters):
         fn()
     e1.record()
@@ -79,11 +102,27 @@ def time_kernel(fn, iters=10, warm=2):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def cpu_baseline(w, params, S, lengths, mask, labels, threads):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, params, S, lengths, mask, labels):
     """Stock-torch port of the reference op sequence on the host cores, fp32, bounded sample."""
     from oracle.torch_ref import TorchRefDiscriminator, fwd_bwd_step
+    host = os.cpu_count() or 1
+    cap_name = "SAD_CPU_THREADS" if os.environ.get("SAD_CPU_THREADS") else ("OMP_NUM_THREADS" if os.environ.get("OMP_NUM_THREADS") else None)
+    threads = min(host, int(os.environ[cap_name])) if cap_name else host
     torch.set_num_threads(threads)
-    sel = torch.arange(0, w["B"], max(1, w["B"] // 128))[:128]            # every k-th sentence: same length mix
+    B = w["B"]
+    # the whole batch when one CPU step stays in the tens of seconds, else every k-th sentence (same length mix)
+    n_s = B if B * w["T"] * w["V"] <= 1024 * 32 * 9353 else 16
+    sel = torch.arange(0, B, max(1, B // n_s))[:n_s]
     m = TorchRefDiscriminator(w["V"], w["E"], w["H"], w["L"]).load_numpy(params)
     for p in m.parameters():
         p.requires_grad = False
@@ -99,9 +138,94 @@ def cpu_baseline(w, params, S, lengths, mask, labels, threads):
             break
     dt = time.perf_counter() - t0
     return dict(value=round(len(sel) * n / dt, 2), unit="sentences/s", cores=threads, kind="port",
-                sample="%d of the %d sentences (every %d-th, same length mix) x %d steps, fp32, "
-                       "oracle/torch_ref.py (stock nn.LSTM/matmul op sequence of the reference)"
-                       % (len(sel), w["B"], max(1, w["B"] // 128), n))
+                host_cpus=host, cpu_model=cpu_model(),
+                thread_cap=("%s=%s" % (cap_name, os.environ[cap_name])) if cap_name else None,
+                sample="%d of the %d sentences (%s) as one batch x %d steps, fp32, oracle/torch_ref.py "
+                       "(stock nn.LSTM/matmul op sequence of the reference)"
+                       % (len(sel), B, "the whole batch" if len(sel) == B else "every %d-th, same length mix" % (B // n_s), n))
+
+
+def kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits, weights):
+    """Every kernel class of SURVEY.md §8 d3 timed in isolation on the step's own workspace through the
+    stage entry points of the C-ABI.  Algorithmic work: DESIGN.md §4."""
+    B, T, V, E, H = w["B"], w["T"], w["V"], w["E"], w["H"]
+    d = lib.dims(B, T, V, E, H, w["L"])
+    pd = lib.padded_dims(d)
+    Ep, Hp, Gp, Ncat = pd["Ep"], pd["Hp"], pd["Gp"], pd["Ncat"]
+    L = lib.load()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    kind = lib.SRC_BF16 if w["s_dtype"] == "bf16" else lib.SRC_F32
+    esz = 2 if w["s_dtype"] == "bf16" else 4
+    M = B * T
+    rows = int((np.arange(T)[:, None] < lengths[None, :]).sum())          # token rows with t < len
+    rows_att = int(np.maximum(lengths.astype(np.int64) - 2, 1).sum())       # attention-active rows (mask: pad/sos/eos)
+    dS = torch.empty_like(S)
+    lg, wt = torch.empty_like(logits), torch.empty_like(weights)
+    ls = torch.empty((B,), dtype=torch.float32, device=S.device)
+    a = lib.SadBwdArgs()
+    a.labels, a.dloss_scale = labels.data_ptr(), 1.0 / B
+    a.logits, a.weights = logits.data_ptr(), weights.data_ptr()
+    D = ctypes.byref(d)
+    calls = [
+        ("K1 soft-embedding fwd (k_tile_list + k_softemb_fwd_sk + k_softemb_fwd_fix)", "mfma+hbm",
+         lambda: L.sad_softemb_fwd(D, p(pw.buf), p(S), kind, V, B * V, p(ws.buf), st()),
+         2.0 * rows * V * E, rows * V * esz + M * Ep * 2),
+        ("K2a+K3 in-projection fwd (k_inproj_fwd_rs2)", "mfma",
+         lambda: L.sad_inproj_fwd(D, p(pw.buf), p(ws.buf), st()),
+         2.0 * rows * E * 9 * H, rows * Ep * 2 + rows * (2 * Gp + Hp) * 4),
+        ("K2b LSTM recurrence fwd (k_lstm_fwd_persist2)", "latency",
+         lambda: L.sad_lstm_fwd(D, p(pw.buf), p(ws.buf), st()),
+         2.0 * rows * H * 4 * H * 2, 0),
+        ("K5 attention+pool+head+CE fwd (k_attn_fwd)", "hbm",
+         lambda: L.sad_attnpool_fwd(D, p(pw.buf), p(labels), p(lg), p(wt), p(ls), p(ws.buf), st()),
+         0.0, rows_att * Hp * 4),
+        ("K5' attention bwd (k_attn_bwd)", "hbm",
+         lambda: L.sad_attnpool_bwd(D, p(pw.buf), ctypes.byref(a), p(ws.buf), st()),
+         0.0, rows_att * Hp * 4 + M * Hp * 2),
+        ("K2' LSTM BPTT (k_lstm_bwd_persist)", "latency",
+         lambda: L.sad_lstm_bwd(D, p(pw.buf), p(ws.buf), st()),
+         2.0 * rows * H * 4 * H * 2, 0),
+        ("K2a'+K3' in-projection bwd (K1 pipeline on dZ)", "mfma",
+         lambda: L.sad_inproj_bwd(D, p(pw.buf), p(ws.buf), st()),
+         2.0 * rows * E * 9 * H, rows * Ncat * 2 + M * Ep * 2),
+        ("K1' soft-embedding bwd (k_softemb_bwd_ws2)", "hbm",
+         lambda: L.sad_softemb_bwd(D, p(pw.buf), p(dS), kind, V, B * V, p(ws.buf), st()),
+         2.0 * rows * V * E, M * V * esz + rows * Ep * 2),
+    ]
+    out = []
+    for name, bound, fn, flops, nbytes in calls:
+        def call(fn=fn, name=name):
+            lib.check(fn(), name)
+        sec = time_launches(call)
+        e = dict(kernel=name, bound=bound, avg_launch_us=round(sec * 1e6, 1))
+        if flops:
+            e["TFLOPs"] = round(flops / sec / 1e12, 1)
+            e["mfma_frac"] = round(flops / sec / 1e12 / MFMA_PEAK_TFS, 4)
+        if nbytes:
+            e["algorithmic_bytes"] = int(nbytes)
+            e["GBps"] = round(nbytes / sec / 1e9, 1)
+            e["hbm_frac"] = round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)
+        if bound == "latency":
+            e["us_per_time_step"] = round(sec * 1e6 / T, 2)
+        out.append(e)
+    ws.check()
+    return out
+
+
+def pmc_counters(kernel_name):
+    """Counters of the committed --pmc passes of THIS command (tools/pmc_bench.sh ->
+    profiles/pmc_bench_traffic.json), only if they were taken from the same sources."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_bench_traffic.json")))
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_bench_traffic.json"
+    if pmc.get("_source_id") != source_id():
+        return None, "profiles/pmc_bench_traffic.json was taken from another build (%s != %s)" % (pmc.get("_source_id"), source_id())
+    for k, v in pmc.items():
+        if not k.startswith("_") and k.split("<")[0] in kernel_name:
+            return v, None
+    return None, "kernel not in the counter file"
 
 
 def main():
@@ -110,8 +234,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--api", default="fused", choices=["fused", "module"])
     ap.add_argument("--s-dtype", default=None, choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table (counter passes)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,44 +249,87 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from sad_amd import functional as Fn, lib, synth
+    from sad_amd import dp, functional as Fn, lib, synth
+    Fn.KEEP_LAST = True                                       # the per-kernel table re-uses the step's workspace
     w = dict(WORKLOADS[a.workload])
     if a.s_dtype:
         w["s_dtype"] = a.s_dtype
+    global_B = w["B"] * world if a.scaling == "weak" else w["B"]
+    if a.scaling == "strong":
+        lo, hi = dp.shard_bounds(w["B"], rank, world)             # contiguous slice of the SAME sorted batch
+        if hi - lo < 1:
+            raise SystemExit("strong scaling: fewer sentences than ranks")
     params = synth.make_params(w["V"], w["E"], w["H"], w["L"], seed=21)
-    pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})
-    S, lengths, ln_dev, mask, labels = make_inputs(w, 1234 + rank, dev)
+    tparams = {k: torch.from_numpy(v).to(dev) for k, v in params.items()}
+    pw = Fn.pack_weights(tparams)
+    if a.scaling == "strong":
+        # every rank generates the same global batch (same seed) and keeps its shard
+        S, lengths, ln_dev, mask, labels = make_inputs(w, 1234, dev, yelp_lengths=a.workload == "yelp64")
+        S = S[:, lo:hi].contiguous()
+        lengths, ln_dev, mask, labels = lengths[lo:hi], ln_dev[lo:hi].contiguous(), mask[lo:hi].contiguous(), labels[lo:hi].contiguous()
+        w["B"] = hi - lo
+    else:
+        S, lengths, ln_dev, mask, labels = make_inputs(w, 1234 + rank, dev, yelp_lengths=a.workload == "yelp64")
     Sv = S.transpose(0, 1).requires_grad_(True)           # [B,T,V] view, exactly like the transfer loop
     B, T, V = w["B"], w["T"], w["V"]
 
-    def step():
-        Sv.grad = None
-        loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
-        loss.mean().backward()
-        return loss
+    if a.api == "module":
+        # the drop-in module as reference transfer/models.py:1172-1212 drives it: CPU int16 lengths,
+        # bool mask, soft=True, un-fused CE against the inverted label
+        from types import SimpleNamespace
+        from sad_amd import transfer_models
+        cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0, enc_num_layers=1,
+                              hidden_size=w["H"], vocab_size=V, emb_size=w["E"], num_labels=w["L"],
+                              freeze_embedding=False, device=str(dev), mask_id=None)
+        model = transfer_models.SelfAttnRNNClassifier(cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        model.to(dev)
+        for p_ in model.parameters():                     # TransferModel.freeze_cls (transfer/models.py:995-999)
+            p_.requires_grad = False
+        len16 = torch.from_numpy(lengths.astype(np.int16))
+        inv_lab = 1 - labels
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+        def step():
+            Sv.grad = None
+            logits, _ = model(Sv, len16, mask.clone(), soft=True)
+            loss = torch.nn.functional.cross_entropy(logits, inv_lab, reduction="none")
+            (loss.sum() / global_B).backward()
+            return loss
+    else:
+        def step():
+            Sv.grad = None
+            loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
+            (loss.sum() / global_B).backward()
+            return loss
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    el = timed(step, a.steps, a.warmup)
 
     # --- unfrozen mode: + parameter gradients, + one all-reduce of the flat grad
     # bucket over RCCL when N > 1, + re-packing the weights (an optimizer step invalidates the image).
-    live = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in params.items() if k in Fn._LIVE_PARAMS}
+    # The all-reduce runs after the backward on the same stream: the persistent recurrences need the
+    # whole device (co-residency), so it is not overlapped with the BPTT (DESIGN.md "Multi-GPU").
+    live = {k: tparams[k].clone().requires_grad_(True) for k in Fn._LIVE_PARAMS}
 
     def step_unfrozen():
         Sv.grad = None
@@ -167,100 +337,83 @@ def main():
             p_.grad = None
         pw.pack(live)
         loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, params=live, pad_id=0)
-        (loss.sum() / (B * world)).backward()
-        if world > 1:
-            dist.all_reduce(Fn._Discriminator.last_grad_bucket)
-        return loss
+        (loss.sum() / global_B).backward()
+        return dp.allreduce_grads(list(live.values()))       # the grads are views of ONE bucket: reduced in place
 
     u_steps = max(1, min(a.steps, 10))
-    for _ in range(2):
-        step_unfrozen()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(u_steps):
-        step_unfrozen()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el_u = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el_u], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el_u = float(tt.item())
+    el_u = timed(step_unfrozen, u_steps, 2)
+    bucket = step_unfrozen()
+    pw.pack(tparams)
     # leave a frozen step's workspace behind for the per-kernel timing below
-    step()
+    Sv.grad = None
+    loss_, logits_, weights_ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
+    (loss_.sum() / global_B).backward()
     torch.cuda.synchronize()
+    ws = Fn._Discriminator.last_workspace
+    ws.check()                                               # hand-off timeout words of the recurrences
 
-    out = None
     if rank == 0:
-        # --- roofline of the dominant kernels, timed in isolation on the launch stream ----------
-        d = lib.dims(B, T, V, w["E"], w["H"], w["L"])
-        ws = Fn._Discriminator.last_workspace                 # need bits + DX of the last step
-        kind = lib.SRC_BF16 if w["s_dtype"] == "bf16" else lib.SRC_F32
-        esz = 2 if w["s_dtype"] == "bf16" else 4
-        L = lib.load()
-        st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        dS = torch.empty_like(S)
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
-        f_fwd = lambda: lib.check(L.sad_softemb_fwd(ctypes.byref(d), p(pw.buf), p(S), kind, V, B * V, p(ws.buf), st()), "softemb_fwd")
-        f_bwd = lambda: lib.check(L.sad_softemb_bwd(ctypes.byref(d), p(pw.buf), p(dS), kind, V, B * V, p(ws.buf), st()), "softemb_bwd")
-        t_fwd, t_bwd = time_kernel(f_fwd), time_kernel(f_bwd)
-        need_rows = int((np.arange(T)[:, None] < lengths[None, :]).sum())
-        M = B * T
-        Ep = lib.padded_dims(d)["Ep"]
-        bytes_fwd = need_rows * V * esz + M * Ep * 2           # read needed S rows once + write X
-        bytes_bwd = M * V * esz + need_rows * Ep * 2           # write every dS row + read dX
-        flops_each = 2.0 * need_rows * V * w["E"]
-        k_fwd = dict(kernel="k_softemb_fwd", seconds=t_fwd, GBps=bytes_fwd / t_fwd / 1e9, TFLOPs=flops_each / t_fwd / 1e12)
-        k_bwd = dict(kernel="k_softemb_bwd", seconds=t_bwd, GBps=bytes_bwd / t_bwd / 1e9, TFLOPs=flops_each / t_bwd / 1e12)
-        dom, dom_bytes = (k_bwd, bytes_bwd) if t_bwd >= t_fwd else (k_fwd, bytes_fwd)
-        roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=round(dom["GBps"], 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(dom["GBps"] / HBM_PEAK_GBS, 4), traffic=None,
-                        algorithmic_bytes=dom_bytes, avg_launch_us=round(dom["seconds"] * 1e6, 1),
-                        mfma_TFLOPs=round(dom["TFLOPs"], 1), mfma_frac=round(dom["TFLOPs"] / MFMA_PEAK_TFS, 4),
-                        other=dict(kernel=(k_fwd if dom is k_bwd else k_bwd)["kernel"],
-                                   avg_launch_us=round((k_fwd if dom is k_bwd else k_bwd)["seconds"] * 1e6, 1),
-                                   GBps=round((k_fwd if dom is k_bwd else k_bwd)["GBps"], 1),
-                                   mfma_TFLOPs=round((k_fwd if dom is k_bwd else k_bwd)["TFLOPs"], 1)))
-        # HBM traffic of the dominant kernel from the committed PMC passes of THIS command
-        # (tools/pmc_bench.sh -> profiles/pmc_bench_traffic.json; FETCH_SIZE doubled per the gfx950 note)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_bench_traffic.json")))
-            key = [k for k in pmc if k.startswith("k_softemb_bwd" if dom is k_bwd else "k_softemb_fwd")]
-            if key and a.workload == "cfg3" and w["s_dtype"] == "bf16":
-                roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        kernels, roofline = None, None
+        if not a.no_kernels:
+            kernels = kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits_.detach(), weights_.detach())
+            dom = max(kernels, key=lambda e: e["avg_launch_us"])
+            if dom["bound"] == "hbm" or (dom["bound"] == "mfma+hbm" and dom.get("hbm_frac", 0) >= dom.get("mfma_frac", 0)):
+                roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=dom["hbm_frac"], algorithmic_bytes=dom["algorithmic_bytes"])
+            else:
+                roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=dom["TFLOPs"], peak=MFMA_PEAK_TFS,
+                                unit="TFLOP/s", frac=dom["mfma_frac"])
+                if dom["bound"] == "latency":
+                    roofline["note"] = ("strictly sequential recurrence: %d dependent steps of %.2f us; MFMA peak is the "
+                                        "only roof it has, hand-off latency is what binds it" % (T, dom["us_per_time_step"]))
+            roofline["avg_launch_us"] = dom["avg_launch_us"]
+            cnt, why = pmc_counters(dom["kernel"])
+            roofline["traffic"] = cnt["hbm_bytes_per_launch"] if cnt and a.workload == "cfg3" and w["s_dtype"] == "bf16" and world == 1 else None
+            if roofline["traffic"] is None:
+                roofline["traffic_note"] = why or "counters are taken on the default workload only"
+            elif "mfma_busy_frac" in cnt:
+                roofline["mfma_busy_frac_pmc"] = cnt["mfma_busy_frac"]
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-            cpu = cpu_baseline(w, params, S, lengths, mask, labels, threads)
+            cpu = cpu_baseline(w, params, S, lengths, mask, labels)
+        units = (B * world if a.scaling == "weak" else global_B)
         out = {
             "metric": "discriminator fwd+bwd sentences/sec (Yelp shape)",
-            "value": round(world * B * a.steps / el, 1), "unit": "sentences/s",
+            "value": round(units * a.steps / el, 1), "unit": "sentences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s: synthetic Yelp-shaped soft tokens, B=%d per GPU, T=%d, V=%d, E=%d, H=%d, "
-                                   "len~U{3..T} sorted, S %s, frozen discriminator (no param grads, no collective)"
-                                   % (a.workload, B, T, V, w["E"], w["H"], w["s_dtype"]),
-                       "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
+                                   "len %s sorted, S %s, frozen discriminator (no param grads, no collective), api=%s"
+                                   % (a.workload, B, T, V, w["E"], w["H"],
+                                      "from data/yelp/dev.* (+sos/eos)" if a.workload == "yelp64" else "~U{3..T}",
+                                      w["s_dtype"], a.api),
+                       "global_batch": units, "seq_len": T, "parallelism": "dp%d" % world,
                        "mfma_inputs": "bf16", "accumulate": "fp32"},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "unfrozen": {"value": round(world * B * u_steps / el_u, 1), "unit": "sentences/s", "steps": u_steps,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "whole_step": {"algorithmic_TFLOP": round(step_flops(w, lengths) / 1e12, 4),
+                           "mfma_frac": round(step_flops(w, lengths) / (el / a.steps) / 1e12 / MFMA_PEAK_TFS, 4)},
+            "unfrozen": {"value": round(units * u_steps / el_u, 1), "unit": "sentences/s", "steps": u_steps,
                          "ms_per_step": round(el_u / u_steps * 1e3, 4),
                          "what": "same batch, + all 19 parameter gradients + weight re-pack"
-                                 + (" + all-reduce of the %.1f MB fp32 grad bucket (RCCL)" % (
-                                     Fn._Discriminator.last_grad_bucket.numel() * 4 / 1e6) if world > 1 else "")},
+                                 + (" + all-reduce of the %.1f MB fp32 grad bucket (RCCL)" % (bucket.numel() * 4 / 1e6)
+                                    if world > 1 else "")},
+            "source_id": source_id(), "sad_version": lib.load().sad_version(),
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def step_flops(w, lengths):
+    """Algorithmic flops of one frozen fwd+bwd step over the rows with t < len (SURVEY.md §8 d3;
+    dead ops excluded): forward K1 + K2a + K2b + K3 per token, backward the same again."""
+    rows = float((np.arange(w["T"])[:, None] < lengths[None, :]).sum())
+    V, E, H = w["V"], w["E"], w["H"]
+    per_token = 2.0 * V * E + 2.0 * E * 8 * H + 2.0 * H * 8 * H + 2.0 * E * H
+    per_sentence = 2.0 * 2 * H * H + 2.0 * H * H + 4.0 * H
+    return 2.0 * (rows * per_token + len(lengths) * per_sentence)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 114 /* 0.1.1 */
+#define SAD_VERSION 200 /* 0.2.0 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -86,10 +86,12 @@ typedef struct sad_fwd_args {
 } sad_fwd_args;
 
 typedef struct sad_bwd_args {
-    const float* dlogits;     /* [B,L] upstream gradient of the logits, or NULL to use CE: */
-    const int64_t* labels;    /*   [B] labels and                                            */
-    const float* dloss;       /*   [B] upstream gradient of the per-sentence loss, or NULL -> */
-    float dloss_scale;        /*   this scalar for every sentence (1/B for `.mean()`)         */
+    /* d logits = dlogits (if given) + dCE(logits, labels)/dlogits * upstream (if labels are given and an
+     * upstream gradient of the per-sentence loss is: dloss, or dloss_scale != 0, or dlogits == NULL). */
+    const float* dlogits;     /* [B,L] upstream gradient of the logits, or NULL */
+    const int64_t* labels;    /* [B] labels of the fused CE, or NULL */
+    const float* dloss;       /* [B] upstream gradient of the per-sentence loss, or NULL -> */
+    float dloss_scale;        /*   this scalar for every sentence (1/B for `.mean()`)     */
     const float* dweights;    /* [B,T] upstream gradient of the attention weights, or NULL */
     const float* logits;      /* [B,L] as written by sad_forward */
     const float* weights;     /* [B,T] as written by sad_forward */
@@ -147,7 +149,8 @@ enum sad_ws_field {
     SAD_WS_ROWS,     /* int32 [3][T*B] compacted lists of contributing token rows (weight gradients) */
     SAD_WS_NROWS,    /* int32 [4]    their lengths */
     SAD_WS_SYNC,     /* u32: hand-off counters of the persistent recurrence (one 128-B line per sentence
-                        tile and direction), then the timeout word (non-zero = a wait timed out) */
+                        tile and direction), then one line with the timeout words: [0] forward recurrence,
+                        [1] BPTT (non-zero = a hand-off wait timed out; the outputs are NaN then) */
     SAD_WS_DZX,      /* bf16 [2][2][B/16][Gp/8][16][8] hand-off image of dZ inside the persistent BPTT */
     SAD_WS_HX,       /* bf16 [2][2][B/16][Hp/8][16][8] hand-off image of h inside the persistent recurrence */
     SAD_WS_K1TILES,  /* int32: count + list of the 128-row tiles with a needed row (stream-K form of K1) */
@@ -211,6 +214,44 @@ int sad_softemb_fwd(const sad_dims* d, const void* packed, const void* src, int3
                     int64_t src_stride_b, int64_t src_stride_t, void* workspace, void* stream);
 int sad_softemb_bwd(const sad_dims* d, const void* packed, void* dsrc, int32_t dsrc_kind,
                     int64_t dsrc_stride_b, int64_t dsrc_stride_t, void* workspace, void* stream);
+/* sad_inproj_fwd:   input projection of both LSTM directions + linear_emb keys in one GEMM (reference
+ *                   transfer/models.py:906 nn.LSTM's W_ih products, :925): workspace X -> G, KK.
+ * sad_inproj_bwd:   its autograd: workspace DZ -> DX.
+ * sad_lstm_fwd:     the packed BiLSTM recurrence (reference transfer/models.py:904-906, ctor :779-785):
+ *                   workspace G (gate pre-activations of the input projection) + LENS -> HS, CS and the
+ *                   activated gates (GA, or G in place when sad_uses_half_gates() == 0).
+ * sad_lstm_bwd:     its BPTT (autograd of :906): workspace DHFIN + saved gates / cell states -> gate columns
+ *                   of DZ.
+ * sad_attnpool_fwd: additive attention + masked softmax + pooling + head (+ CE) (reference
+ *                   transfer/models.py:855-880, :949, CE :990,:1212): workspace KK, U, NEED -> logits,
+ *                   weights, loss (NULL to skip), CTX.
+ * sad_attnpool_bwd: its backward: -> key columns of DZ, DU and the per-sentence pieces of the head's
+ *                   parameter gradients; `a` as for sad_backward (dsrc / drop_keep ignored).
+ * All six work on a workspace that a sad_forward (and, for the backward stages, the stages in front
+ * of them in sad_backward's order) has filled. */
+int sad_inproj_fwd(const sad_dims* d, const void* packed, void* workspace, void* stream);
+int sad_inproj_bwd(const sad_dims* d, const void* packed, void* workspace, void* stream);
+int sad_lstm_fwd(const sad_dims* d, const void* packed, void* workspace, void* stream);
+int sad_lstm_bwd(const sad_dims* d, const void* packed, void* workspace, void* stream);
+int sad_attnpool_fwd(const sad_dims* d, const void* packed, const int64_t* labels, float* logits, float* weights,
+                     float* loss, void* workspace, void* stream);
+int sad_attnpool_bwd(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* workspace, void* stream);
+
+/* Test / diagnosis settings (process-wide; no counterpart in the reference).  Do not change them
+ * between a sad_forward and its sad_backward.
+ *   SAD_DBG_NO_PERSIST    1: run the recurrences as one launch per time step (also: SAD_NO_PERSIST=1 in
+ *                         the environment at the first call), 0: persistent kernels when they fit;
+ *   SAD_DBG_SPIN_LIMIT    bound (poll iterations) of a hand-off wait inside the persistent recurrences,
+ *                         <= 0 restores the default;
+ *   SAD_DBG_WITHHOLD_FWD  index of a workgroup of the persistent forward recurrence that exits at once,
+ *   SAD_DBG_WITHHOLD_BWD  the same for the persistent BPTT (-1: none): forces the hand-off timeout path,
+ *                         which must end in NaN logits / loss / d(soft tokens) and a raised timeout word
+ *                         in SAD_WS_SYNC, never in silently wrong numbers. */
+#define SAD_DBG_NO_PERSIST 0
+#define SAD_DBG_SPIN_LIMIT 1
+#define SAD_DBG_WITHHOLD_FWD 2
+#define SAD_DBG_WITHHOLD_BWD 3
+int sad_debug_set(int32_t key, int64_t value);
 
 #ifdef __cplusplus
 }

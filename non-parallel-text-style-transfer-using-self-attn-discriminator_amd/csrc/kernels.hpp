@@ -193,159 +193,11 @@ __global__ __launch_bounds__(C::NT) void k_softemb_fwd(Shape s, const void* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1 with LOADER and COMPUTE waves (large batches, Ep = 320): 768 threads per 128-row tile.
-//   waves 0-7  compute: fragments from LDS, 40 MFMAs per 64-deep k-tile, no vector-memory
-//              instruction until the epilogue;
-//   waves 8-11 loaders: S tile [128][64] (fp32 -> bf16 on the way, 2-/4-byte aligned rows) and
-//              W_emb^T tile [320][64] of k-tile k+1 into the spare LDS buffer while k is multiplied,
-//              two register sets so two k-tiles of loads are in flight.
-// One workgroup barrier per k-tile.  In the single-role kernel every wave alternates between
-// staging (global loads, LDS writes) and multiplying, and the phases add up (2 us per k-tile
-// against 0.55 us of MFMA).
-// ------------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(768) void k_softemb_fwd_ws(Shape s, const void* __restrict__ src, long long sT, long long sB,
-                                                       const unsigned char* __restrict__ need,
-                                                       const bf16raw* __restrict__ wembT, bf16raw* __restrict__ X) {
-    typedef Cfg<128, 320, 2, 4, 1> C;
-    typedef SoftRow<KIND> SR;
-    typedef typename SR::Elem Elem;
-    constexpr int ABYTES = 128 * 128, BBYTES = 320 * 128, BUF = ABYTES + BBYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];     // 2 * BUF
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 128;
-    const int M = s.M, V = s.V, Vp = s.Vp;
-    {   // tiles nobody reads are skipped (every wave takes the same decision)
-        int any = 0;
-        for (int r = tid; r < 128; r += 768)
-            if (m0 + r < M && need[m0 + r]) any = 1;
-        if (!__syncthreads_or(any)) return;
-    }
-    const int nk = (V + 63) / 64;
-    if (wave >= 8) {
-        // ---------------------------------- loader waves ---------------------------------------
-        const int lt = tid - 512;
-        // chunk (lt + 256 i) = tile row lt/8 + 32 i, 16-byte chunk lt%8: the LDS swizzle depends on
-        // (row >> 1) & 7 only, so row + 32 i keeps it and every offset is base + i * constant.
-        const int r0 = lt >> 3, c0 = lt & 7;
-        const Elem* arow[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + r0 + 32 * i;
-            arow[i] = nullptr;
-            if (m < M && need[m]) {
-                const int t = m / s.B, b = m - t * s.B;
-                arow[i] = (const Elem*)src + (long long)t * sT + (long long)b * sB + c0 * 8;
-            }
-        }
-        const int aoff0 = lds_off<C>(r0, c0) * 2, boff0 = ABYTES + aoff0;
-        const bf16raw* brow0 = wembT + (long long)r0 * Vp + c0 * 8;
-        const long long bstep = 32ll * Vp;
-        typename SR::Raw ra[2][4];
-        u32x4 rb[2][10];
-        const Elem* dummy = (const Elem*)src;
-        const int nkf = V / 64;                                // whole k-tiles: unguarded, branch-free loads
-        auto load_tile = [&](auto par, int kt) {               // clamped, never skipped: static operation counts
-            constexpr int P = decltype(par)::value;
-            const int k0 = (kt < nkf ? kt : nkf - 1) * 64;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_fast(arow[i], dummy, k0);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) rb[P][i] = *(const u32x4*)(brow0 + i * bstep + k0);
-        };
-        auto to_lds = [&](auto par, int kt) {
-            constexpr int P = decltype(par)::value;
-            unsigned char* buf = fw_lds + (kt & 1) * BUF;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *(u32x4*)&buf[aoff0 + i * 4096] = typename SR::Cvt()(ra[P][i]);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) *(u32x4*)&buf[boff0 + i * 4096] = rb[P][i];
-        };
-        auto tail_to_lds = [&](int kt) {                       // the ragged last k-tile: element-guarded loads
-            unsigned char* buf = fw_lds + (kt & 1) * BUF;
-            const int k0 = kt * 64;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *(u32x4*)&buf[aoff0 + i * 4096] =
-                    typename SR::Cvt()(SR::load(arow[i] != nullptr ? arow[i] - c0 * 8 : nullptr, k0 + c0 * 8, V));
-#pragma unroll
-            for (int i = 0; i < 10; ++i) *(u32x4*)&buf[boff0 + i * 4096] = *(const u32x4*)(brow0 + i * bstep + k0);
-        };
-        using P0 = std::integral_constant<int, 0>;
-        using P1 = std::integral_constant<int, 1>;
-        int kt = 0;
-        if (nkf >= 1) {
-            load_tile(P0{}, 0);
-            load_tile(P1{}, 1);
-            to_lds(P0{}, 0);
-            load_tile(P0{}, 2);
-        } else {
-            tail_to_lds(0);
-        }
-        __syncthreads();                                       // k-tile 0 ready
-        // steady state, branch-free: while k-tiles kt, kt+1 are multiplied, kt+1 and kt+2 (whole tiles)
-        // go to LDS and kt+3, kt+4 are requested
-        for (; kt + 3 < nkf; kt += 2) {
-            to_lds(P1{}, kt + 1);
-            load_tile(P1{}, kt + 3);
-            __syncthreads();
-            to_lds(P0{}, kt + 2);
-            load_tile(P0{}, kt + 4);
-            __syncthreads();
-        }
-        // last few k-tiles: set (j+1)&1 still holds whole tile j+1; the ragged tail is loaded here
-        for (int j = kt; j < nk; ++j) {
-            if (j + 1 < nkf) {
-                if ((j + 1) & 1) to_lds(P1{}, j + 1);
-                else to_lds(P0{}, j + 1);
-            } else if (j + 1 < nk) {
-                tail_to_lds(j + 1);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // -------------------------------------- compute waves ----------------------------------------
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    f32x4 acc[C::TM][C::TN];
-    zero_acc<C>(acc);
-    __syncthreads();                                           // k-tile 0 ready
-    for (int kt = 0; kt < nk; ++kt) {
-        const bf16raw* As = (const bf16raw*)(fw_lds + (kt & 1) * BUF);
-        const bf16raw* Bs = (const bf16raw*)(fw_lds + (kt & 1) * BUF + ABYTES);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[C::TM], bfr[C::TN];
-            const int ch = kk * 4 + (lane >> 4);
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) af[tm] = *(const bf16x8*)&As[lds_off<C>(frag_row<C>(wm, tm, lane), ch)];
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
-                bfr[tn] = *(const bf16x8*)&Bs[lds_off<C>(wn * (C::BN / C::WN) + tn * 16 + (lane & 15), ch)];
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
-        }
-        __syncthreads();                                       // k-tile kt consumed; kt+1 written by the loaders
-    }
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        const int m = m0 + frag_row<C>(wm, tm, lane);
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int n = frag_col<C>(wn, tn, lane);
-            if (m < M && n < s.Ep) *(u32x2*)&X[(long long)m * s.Ep + n] = pack_bf16x4(acc[tm][tn]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K1, three wave roles (large batches, Ep = 320): the two operand streams have different latencies
 // (S comes from HBM, ~2.3 us under load; W_emb^T from L2), and vmcnt retires in order inside a wave,
 // so one loader wave cannot keep different depths in flight for them.
-//   waves 0-7   compute (as in k_softemb_fwd_ws);
+//   waves 0-7   compute: fragments from LDS, 40 MFMAs per 64-deep k-tile, no vector-memory
+//               instruction until the epilogue;
 //   waves 8-11  S loaders: register-staged (dtype conversion, 2-/4-byte aligned rows), D k-tiles of
 //               loads in flight (4 for bf16 S, 2 for fp32 S), two LDS stages;
 //   waves 12-15 W loaders: LDS-direct loads (global_load_lds_dwordx4, no registers), three LDS
@@ -1170,7 +1022,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(Shape s, const float* __restri
                                                  const float* __restrict__ ba, const float* __restrict__ wo,
                                                  const float* __restrict__ bo, const long long* __restrict__ labels,
                                                  float* __restrict__ weights, float* __restrict__ ctx_out,
-                                                 float* __restrict__ logits, float* __restrict__ loss) {
+                                                 float* __restrict__ logits, float* __restrict__ loss,
+                                                 const unsigned* __restrict__ errword) {
     __shared__ float sc[ATT_MAX_T];
     __shared__ float wm_[4], wl_[4];
     __shared__ __attribute__((aligned(16))) float cx[4][NV * 256];
@@ -1228,6 +1081,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(Shape s, const float* __restri
         gl += wl_[k] * sw[k];
     }
     // gl == 0: every position masked -> softmax of all -inf is NaN in the reference; mirror it.
+    // A hand-off wait of the persistent recurrence timed out (errword, zeroed by k_prep of this call):
+    // h may be stale for some sentences -> every sentence's weights / logits / loss come out NaN.
+    if (errword != nullptr && *errword != 0u) gl = 0.f;
     const float inv = gl > 0.f ? 1.0f / gl : __builtin_nanf("");
     for (int t = tid; t < T; t += 256) {
         const long long m = (long long)t * B + b;
@@ -1289,9 +1145,9 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Hp = s.Hp, B = s.B, T = s.T, L = s.L;
     if (tid == 0) {
-        if (dlogits != nullptr) {
-            for (int c = 0; c < L; ++c) dl[c] = dlogits[(long long)b * L + c];
-        } else {
+        for (int c = 0; c < L; ++c) dl[c] = dlogits != nullptr ? dlogits[(long long)b * L + c] : 0.f;
+        if (labels != nullptr && (dlogits == nullptr || dloss != nullptr || dloss_scale != 0.f)) {
+            // + d CE(logits, labels) scaled by the upstream gradient of the per-sentence loss
             const float up = dloss != nullptr ? dloss[b] : dloss_scale;
             float m2 = -INFINITY;
             for (int c = 0; c < L; ++c) m2 = fmaxf(m2, logits[(long long)b * L + c]);
@@ -1299,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
             for (int c = 0; c < L; ++c) se += __expf(logits[(long long)b * L + c] - m2);
             const long long lab = labels[b];
             for (int c = 0; c < L; ++c)
-                dl[c] = (__expf(logits[(long long)b * L + c] - m2) / se - (c == lab ? 1.f : 0.f)) * up;
+                dl[c] += (__expf(logits[(long long)b * L + c] - m2) / se - (c == lab ? 1.f : 0.f)) * up;
         }
     }
     __syncthreads();
@@ -1755,63 +1611,6 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
     }
 }
 
-// K1' fast path: dS[m][v] = sum_e dX[m][e] * W_emb[v][e], every (m, v) written in the caller's
-// dtype/strides (rows with t >= len come out as exact zeros because their dX rows are zero).
-template <int KS, int KIND>
-__global__ __launch_bounds__(512) void k_softemb_bwd_rs(Shape s, const bf16raw* __restrict__ DX,
-                                                       const unsigned char* __restrict__ need,
-                                                       const bf16raw* __restrict__ wemb, void* __restrict__ dS,
-                                                       long long sT, long long sB, int nt_per) {
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * KS * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 256;
-    const int ntiles = s.Vp / 64;
-    const int nt0 = blockIdx.y * nt_per;
-    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
-    const int M = s.M, V = s.V;
-    int mrow[2];
-    long long obase[2];
-    int rneed = 0;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        const int m = m0 + wave * 32 + tm * 16 + (lane & 15);
-        mrow[tm] = m;
-        obase[tm] = 0;
-        if (m < M) {
-            const int t = m / s.B, b = m - t * s.B;
-            obase[tm] = (long long)t * sT + (long long)b * sB;
-            rneed |= need[m];
-        }
-    }
-    const bool wave_any = __any(rneed != 0);
-    const int block_any = __syncthreads_or(rneed != 0);
-    if constexpr (KIND == SRC_F32) {
-        rs_gemm<KS, false>(DX, M, mrow, wave_any, block_any, wemb, nt0, nt1, Bs, [&](int tm, int n, f32x4 v) {
-            if (mrow[tm] >= M || n >= V) return;
-            float* p = (float*)dS + obase[tm] + n;
-            if (n + 4 <= V) {
-                *(f32x4u*)p = v;
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < V) p[e] = v[e];
-            }
-        });
-    } else {
-        rs_gemm<KS, true>(DX, M, mrow, wave_any, block_any, wemb, nt0, nt1, Bs, [&](int tm, int n, f32x4 lo, f32x4 hi) {
-            if (mrow[tm] >= M || n >= V) return;
-            bf16raw* p = (bf16raw*)dS + obase[tm] + n;
-            if (n + 8 <= V) {
-                *(u32x4h*)p = pack_bf16x8(lo, hi);
-            } else {
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e < V) p[e] = f32_to_bf16(lo[e]);
-                    if (n + 4 + e < V) p[4 + e] = f32_to_bf16(hi[e]);
-                }
-            }
-        });
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Wave-specialised form of rs_gemm (K1'): 8 COMPUTE waves (A fragments in registers, MFMAs,
 // epilogue stores) + 4 LOADER waves (Bt tiles -> LDS) in one 768-thread workgroup.
@@ -1931,7 +1730,8 @@ __device__ __forceinline__ void rs_gemm_ws(const bf16raw* __restrict__ A, int M,
     }
 }
 
-// K1' on rs_gemm_ws.  Same contract as k_softemb_bwd_rs.
+// K1' on rs_gemm_ws (Ep == 32*KS): dS[m][v] = sum_e dX[m][e] * W_emb[v][e], every (m, v) written in the
+// caller's dtype/strides (rows with t >= len come out as exact zeros because their dX rows are zero).
 template <int KS, int KIND>
 __global__ __launch_bounds__(768) void k_softemb_bwd_ws(Shape s, const bf16raw* __restrict__ DX,
                                                        const unsigned char* __restrict__ need,
@@ -2178,41 +1978,6 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
     K1P_OUT2("compute: -, MFMA + LDS write, barrier")
 }
 
-// K2a + K3 fast path (Ep == 32*KS, Ncat % 64 == 0): [G | Kk][m] = X[m] . Wcat^T + bcat.
-// Rows nobody reads (need == 0) are not written.
-template <int KS>
-__global__ __launch_bounds__(512) void k_inproj_fwd_rs(Shape s, const bf16raw* __restrict__ X,
-                                                      const unsigned char* __restrict__ need,
-                                                      const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
-                                                      float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * KS * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 256;
-    const int ntiles = s.Ncat / 64;
-    const int nt0 = blockIdx.y * nt_per;
-    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
-    const int M = s.M, G2 = 2 * s.Gp;
-    int mrow[2];
-    bool rn[2];
-    int rneed = 0;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        const int m = m0 + wave * 32 + tm * 16 + (lane & 15);
-        mrow[tm] = m;
-        rn[tm] = m < M && need[m] != 0;
-        rneed |= rn[tm] ? 1 : 0;
-    }
-    const bool wave_any = __any(rneed != 0);
-    const int block_any = __syncthreads_or(rneed != 0);
-    if (!block_any) return;
-    rs_gemm<KS, false>(X, M, mrow, wave_any, block_any, wcat, nt0, nt1, Bs, [&](int tm, int n, f32x4 v) {
-        if (!rn[tm]) return;
-        v += *(const f32x4*)&bcat[n];
-        float* p = n < G2 ? G + (long long)mrow[tm] * s.Gld + n : Kk + (long long)mrow[tm] * s.Hp + (n - G2);
-        *(f32x4*)p = v;
-    });
-}
-
 // K2a + K3, A-stationary, with the output tile turned through a wave-private LDS scratch: the
 // accumulator layout gives 16-byte pieces of 16 different rows per quarter wave; after the turn a
 // store instruction writes full 256-byte row segments of 4 rows.  No extra workgroup barrier: a
@@ -2277,171 +2042,6 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* 
 #endif
         }
     });
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2a + K3 with LOADER, COMPUTE and STORE waves (768 threads, Ep == 32*KS, Ncat % 32 == 0).
-// The kernel is bound by its fp32 output (rows x Ncat x 4 bytes); the accumulator layout only gives
-// 16-byte pieces of 16 different rows per quarter wave, which the memory pipe takes at a fraction of
-// its rate.  Same treatment as K1' (k_softemb_bwd_ws2):
-//   waves 0-7   compute: X fragments of 256 rows in registers, 40 MFMAs per 32-column tile, results
-//               -> LDS output tile [256][32] fp32;
-//   waves 8-9   loaders: Wcat tile nt+1 (20 KB, contiguous) -> LDS while tile nt is multiplied;
-//   waves 10-11 storers: tile nt-1 from LDS (+ bias) -> G / Kk as full 128-byte row segments, 8 rows per
-//               instruction.  Rows nobody reads (need == 0) are not written.
-// LDS: 2 x 20 KB Wcat tiles + 2 x 32 KB output tiles, one workgroup barrier per tile.
-// ------------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(768) void k_inproj_fwd_ws2(Shape s, const bf16raw* __restrict__ X,
-                                                       const unsigned char* __restrict__ need,
-                                                       const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
-                                                       float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
-    constexpr int EP = KS * 32, BN = 32;
-    constexpr int ROWB = EP * 2, CPR = EP / 8, TILEB = BN * ROWB;
-    constexpr int NLOAD = 128, SCH = BN * CPR / NLOAD;        // loader threads, chunks per thread and tile
-    constexpr int OUTB = 256 * BN * 4;                        // one output tile: [256][32] fp32, 128-byte rows
-    static_assert((BN * CPR) % NLOAD == 0, "tile must split evenly over the loader waves");
-    extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
-    unsigned char* Bs = ip_lds;                                // 2 x TILEB
-    unsigned char* Os = ip_lds + 2 * TILEB;                    // 2 x OUTB, chunk c of row r at r*128 + ((c ^ (r&7)) << 4)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 256;
-    const int ntiles = s.Ncat / BN;
-    const int nt0 = blockIdx.y * nt_per;
-    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
-    const int ntl = nt1 - nt0;
-    const int M = s.M, G2 = 2 * s.Gp;
-    {   // row blocks nobody reads are skipped (every wave takes the same decision)
-        int any = 0;
-        for (int r = tid; r < 256; r += 768)
-            if (m0 + r < M && need[m0 + r]) any = 1;
-        if (!__syncthreads_or(any) || ntl <= 0) return;
-    }
-
-    if (wave >= 10) {
-        // -------------------------------------- store waves --------------------------------------
-        const int ls = tid - 640, c = ls & 7;
-        int mrow[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = m0 + (ls >> 3) + 16 * i;
-            mrow[i] = (m < M && need[m]) ? m : -1;
-        }
-        __syncthreads();                                       // prologue barrier
-        for (int it = 0; it <= ntl; ++it) {
-            if (it >= 1) {
-                const unsigned char* buf = Os + ((it - 1) & 1) * OUTB;
-                const int n = (nt0 + it - 1) * BN + c * 4;
-                const f32x4 bias = *(const f32x4*)&bcat[n];
-                float* base = n < G2 ? G + n : Kk + (n - G2);
-                const long long ld = n < G2 ? s.Gld : s.Hp;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = (ls >> 3) + 16 * i;
-                    const f32x4 v = *(const f32x4*)&buf[r * 128 + ((c ^ (r & 7)) << 4)];
-                    if (mrow[i] >= 0) *(f32x4*)(base + (long long)mrow[i] * ld) = v + bias;
-                }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    if (wave >= 8) {
-        // -------------------------------------- loader waves -------------------------------------
-        const int lt = tid - 512;
-        int soff[SCH], goff[SCH];
-#pragma unroll
-        for (int i = 0; i < SCH; ++i) {
-            const int g = lt + i * NLOAD;
-            const int rho = g / CPR, ch = g - rho * CPR;
-            soff[i] = rho * ROWB + ((ch ^ ((rho >> 1) & 7)) << 4);
-            goff[i] = g * 8;
-        }
-        u32x4 st[SCH];
-        auto load_tile = [&](int k) {                          // clamped, never skipped
-            const bf16raw* base = wcat + (long long)(nt0 + (k < ntl ? k : ntl - 1)) * BN * EP;
-#pragma unroll
-            for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
-        };
-        auto to_lds = [&](int k) {
-            unsigned char* buf = Bs + (k & 1) * TILEB;
-#pragma unroll
-            for (int i = 0; i < SCH; ++i) *(u32x4*)&buf[soff[i]] = st[i];
-        };
-        load_tile(0);
-        to_lds(0);
-        load_tile(1);
-        __syncthreads();                                       // prologue barrier: tile 0 ready
-        for (int it = 0; it <= ntl; ++it) {
-            if (it + 1 < ntl) {
-                to_lds(it + 1);
-                load_tile(it + 2);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // ---------------------------------------- compute waves --------------------------------------
-    int mrow[2];
-    int rneed = 0;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        mrow[tm] = m0 + wave * 32 + tm * 16 + (lane & 15);
-        if (mrow[tm] < M) rneed |= need[mrow[tm]];
-    }
-    const bool wave_any = __any(rneed != 0);
-    bf16x8 a[2][KS];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (wave_any && mrow[tm] < M) v = *(const u32x4*)(X + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
-            a[tm][ks] = __builtin_bit_cast(bf16x8, v);
-        }
-    int roff[2], rsw[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int rho = tn * 16 + (lane & 15);
-        roff[tn] = rho * ROWB;
-        rsw[tn] = (rho >> 1) & 7;
-    }
-    __syncthreads();                                           // prologue barrier
-    for (int it = 0; it <= ntl; ++it) {
-        if (it < ntl) {
-            const unsigned char* buf = Bs + (it & 1) * TILEB;
-            unsigned char* ob = Os + (it & 1) * OUTB;
-            f32x4 acc[2][2];
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (wave_any) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 bfr[2];
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        bfr[tn] = *(const bf16x8*)&buf[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
-#pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < 2; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int r = wave * 32 + tm * 16 + (lane & 15);
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    const int c = tn * 4 + (lane >> 4);        // columns 16 tn + 4 (lane >> 4) .. + 3
-                    *(f32x4*)&ob[r * 128 + ((c ^ (r & 7)) << 4)] = acc[tm][tn];
-                }
-            }
-        }
-        __syncthreads();
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -4,14 +4,10 @@
 // Why: one launch per step pays a kernel boundary, a cold W_hh read and a G/Cs round trip per
 // step; the steps are tiny (4.3 GFLOP) and strictly sequential, so those fixed costs dominate.
 //
-// Decomposition (B = 1024, H = 512: 8 x 2 x 16 = 256 workgroups = one per CU):
-//   * a workgroup owns 128 sentences x 128 permuted gate columns (= 32 hidden units x 4 gates) of
-//     one direction for the WHOLE sequence.  Its W_hh slice [128][Hp] bf16 (128 KB) is loaded into
-//     LDS once; the cell state of its (sentence, unit) pairs never leaves registers.
-//   * per step only h_{t-1} of its 128 sentences (all Hp units, written by the 16 workgroups of the
-//     same sentence tile and direction = a "group") is read: 128 KB from L2 / fabric.
-//   * the only synchronisation is inside a group (16 workgroups), never grid-wide; sentence tiles
-//     advance independently, and a tile of short sentences simply stops early.
+// Decomposition: see the two kernels below (forward: 128 sentences x 16 hidden units per workgroup, two
+// workgroups per CU; BPTT: 128 sentences x 32 units, one per CU).  The workgroups that share a
+// sentence tile and a direction form a "group"; the only synchronisation is inside a group, never
+// grid-wide; sentence tiles advance independently, and a tile of short sentences simply stops early.
 //
 // Hand-off of h between workgroups INSIDE the launch follows cdna_hip_programming.md Guideline 16 /
 // MI355X_MICROARCH.md "Valid forms" row 1, in the form that needs no cache-wide fence:
@@ -25,7 +21,10 @@
 // Counters are zeroed in front of every launch by a kernel of the same call that runs earlier on the
 // stream (k_prep in the forward, k_attn_bwd in the backward: a separate memset node cost 4.5 us).  All workgroups must be
 // co-resident: the host checks the grid against the occupancy query and otherwise runs the
-// one-launch-per-step kernels.  Spins are bounded: a timeout sets the error word and ends waiting.
+// one-launch-per-step kernels.  Spins are bounded: a timeout raises the error word (checked by
+// k_attn_fwd, which then writes NaN logits / loss for the whole batch, and by the host helpers) and
+// the workgroup publishes NaN from then on, so logits and dS cannot come out silently wrong.  No
+// other kernel may occupy CUs of the device while a persistent launch is in flight.
 #pragma once
 #include "kernels.hpp"
 
@@ -90,219 +89,29 @@ __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigne
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
 }
 
-constexpr int LP_BM = 128, LP_BN = 128, LP_KT_MAX = 8;       // tile; Hp <= 64 * LP_KT_MAX
+constexpr int LP_BM = 128;                                   // sentences per tile (= LF_BM = LB_BM)
 constexpr int LP_SYNC_PITCH = 32;                            // counter pitch in 4-byte words (128-B lines)
-constexpr unsigned LP_SPIN_LIMIT = 1u << 22;
-
-__host__ __device__ inline size_t lstm_persist_lds_bytes(int Hp) { return (size_t)LP_BN * Hp * 2 + 2 * LP_BM * 64 * 2; }
+constexpr unsigned LP_SPIN_LIMIT = 1u << 22;                 // default bound of a hand-off wait (~seconds)
+constexpr unsigned LP_NAN2 = 0x7fc07fc0u;                    // two bf16 quiet NaNs
 
 // 16-byte chunk swizzle of the resident W image (rows of Hp bf16): conflict-free b128 fragment
 // reads when a row has a multiple of 16 chunks, 4-way otherwise.
 __device__ __forceinline__ int lp_wswz(int col, int chunk, int cmask) { return chunk ^ (col & cmask); }
 
-__global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __restrict__ lens,
-                                                         const bf16raw* __restrict__ whh, float* __restrict__ G,
-                                                         float* __restrict__ Cs, bf16raw* Hs, unsigned* sync) {
-    typedef Cfg<LP_BM, LP_BN, 4, 2, 1> C;                   // 8 waves: 32 rows x one 64-column gate block each
-    extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
-    const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
-    bf16raw* Wl = (bf16raw*)lp_lds;                          // [128][Hp], chunk-swizzled
-    bf16raw* As = (bf16raw*)(lp_lds + (size_t)LP_BN * Hp * 2);   // 2 x [128][64], gemm_core swizzle
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ctiles = Gp / LP_BN, rtiles = (B + LP_BM - 1) / LP_BM, groups = rtiles * 2;
-    int group, ct;
-    if (groups % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only): keep a group on one XCD
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        group = xcd + 8 * (slot / ctiles);
-        ct = slot % ctiles;
-    } else {
-        group = blockIdx.x / ctiles;
-        ct = blockIdx.x % ctiles;
-    }
-    const int dir = group & 1, b0 = (group >> 1) * LP_BM, n0 = ct * LP_BN;
-    gu32* counter = (gu32*)(sync + (size_t)group * LP_SYNC_PITCH);
-    gu32* errword = (gu32*)(sync + (size_t)groups * LP_SYNC_PITCH);
-    const int cpr = Hp / 8;                                  // 16-byte chunks per W row
-    const int cmask = (cpr % 16 == 0) ? 15 : 3;
-
-    // ---- once: W_hh slice -> LDS; longest sentence of the tile ------------------------------------
-    {
-        const bf16raw* w = whh + ((long long)dir * Gp + n0) * Hp;
-        for (int idx = tid; idx < LP_BN * cpr; idx += 512) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            *(u32x4*)(Wl + (long long)r * Hp + lp_wswz(r, c, cmask) * 8) = *(const u32x4*)(w + (long long)r * Hp + c * 8);
-        }
-    }
-    int maxlen = 0;
-    for (int r = tid; r < LP_BM; r += 512) maxlen = (b0 + r < B) ? lens[b0 + r] : 0;
-    {
-        int* red_max = (int*)As;             // all LDS is dynamic (16-B aligned base); As is not in use yet
-        if (tid == 0) *red_max = 0;
-        __syncthreads();
-        if (maxlen > 0) atomicMax(red_max, maxlen);
-        __syncthreads();
-        maxlen = *red_max;
-    }
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int col0 = n0 + wn * 64;                           // first permuted column of this wave's unit block
-    const int u4 = (lane >> 4) * 4;
-    const int j = (col0 >> 6) * 16 + u4;                     // first of this lane's 4 hidden units
-    int brow[C::TM], blen[C::TM];
-    f32x4 creg[C::TM];
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        brow[tm] = b0 + frag_row<C>(wm, tm, lane);
-        blen[tm] = brow[tm] < B ? lens[brow[tm]] : 0;
-        creg[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // staging rows of this thread: chunk g = tid + i*512 -> row g/8, 16-byte chunk g%8 of a 64-wide k-tile
-    int srow[2], slen[2];
-    const int skc = (tid & 7) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        srow[i] = b0 + (tid >> 3) + i * 64;
-        slen[i] = srow[i] < B ? lens[srow[i]] : 0;
-    }
-    const int nkt = (Hp + 63) / 64;
-    unsigned done = 0;                                       // active steps this group has completed
-    bool dead = false;                                       // a spin timed out: stop waiting
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? T - 1 - step : step;
-        if (!(maxlen > t)) continue;                         // group-uniform: no sentence of the tile is alive
-        const int tp = dir ? t + 1 : t - 1;
-        // gate pre-activations of this step: private to the workgroup, independent of h -> issued first
-        f32x4 pre[C::TM][4];
-        bool act[C::TM];
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-            act[tm] = blen[tm] > t;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pre[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (act[tm]) {
-                const float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + col0 + u4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pre[tm][q] = *(const f32x4*)(g + 16 * q);
-            }
-        }
-        f32x4 acc[C::TM][C::TN];
-        zero_acc<C>(acc);
-        if (done > 0) {
-            // ---- wait for h_{tp} of the whole group -------------------------------------------------
-            if (tid == 0 && !dead) {
-                const unsigned target = done * (unsigned)ctiles;
-                unsigned spins = 0;
-                while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > LP_SPIN_LIMIT) {
-                        __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
-                        dead = true;
-                        break;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
-            __syncthreads();
-            // ---- all of this tile's h_{tp} in flight at once (16-byte sc1 loads) -----------------------
-            u32x4 a[LP_KT_MAX][2];
-            {
-                const __amdgpu_buffer_rsrc_t rs = lp_rsrc(Hs + (long long)tp * B * 2 * Hp, (unsigned)B * 2u * Hp * 2u);
-#pragma unroll
-                for (int kt = 0; kt < LP_KT_MAX; ++kt)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int k = kt * 64 + skc;
-                        const bool ok = slen[i] > tp && k < Hp;
-                        a[kt][i] = lp_load16_sc1(rs, ok ? (unsigned)(((srow[i] - 0) * 2 + dir) * Hp + k) * 2u : LP_OOB);
-                    }
-            }
-            // ---- gates += h_{tp} . W_hh^T against the resident slice -----------------------------------
-            // k-tile kt+1 is written into the other As buffer while kt is multiplied: one barrier per k-tile.
-            auto stage = [&](int kt, const u32x4 (&ak)[2]) {
-                bf16raw* buf = As + (kt & 1) * (LP_BM * 64);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) *(u32x4*)&buf[lds_off<C>((tid >> 3) + i * 64, skc >> 3)] = ak[i];
-            };
-            __syncthreads();                                 // As free (previous step / prologue done with it)
-            stage(0, a[0]);
-            __syncthreads();
-#pragma unroll
-            for (int kt = 0; kt < LP_KT_MAX; ++kt) {
-                if (kt < nkt) {
-                    if (kt + 1 < LP_KT_MAX && kt + 1 < nkt) stage(kt + 1, a[kt + 1 < LP_KT_MAX ? kt + 1 : 0]);
-                    const bf16raw* buf = As + (kt & 1) * (LP_BM * 64);
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        if (kt * 64 + kk * 32 < Hp) {
-                            bf16x8 af[C::TM], bfr[C::TN];
-                            const int ch = kk * 4 + (lane >> 4);
-#pragma unroll
-                            for (int tm = 0; tm < C::TM; ++tm)
-                                af[tm] = *(const bf16x8*)&buf[lds_off<C>(frag_row<C>(wm, tm, lane), ch)];
-#pragma unroll
-                            for (int tn = 0; tn < C::TN; ++tn) {
-                                const int col = wn * 64 + tn * 16 + (lane & 15);
-                                bfr[tn] = *(const bf16x8*)(Wl + (long long)col * Hp + lp_wswz(col, kt * 8 + ch, cmask) * 8);
-                            }
-#pragma unroll
-                            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                                for (int tn = 0; tn < C::TN; ++tn)
-                                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[tm], acc[tm][tn], 0, 0, 0);
-                        }
-                    }
-                    __syncthreads();                         // kt consumed by all; kt+1 written by all
-                }
-            }
-        }
-        // ---- cell update; publish h_t first, the private stores (gates, c) after the signal -----------
-        f32x4 gi[C::TM], gf[C::TM], gg[C::TM], go[C::TM];
-        u32x2 hp[C::TM];
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-            hp[tm] = u32x2{0u, 0u};
-            if (!act[tm]) continue;
-            const f32x4 pi = acc[tm][0] + pre[tm][0], pf = acc[tm][1] + pre[tm][1];
-            const f32x4 pg = acc[tm][2] + pre[tm][2], po = acc[tm][3] + pre[tm][3];
-            const f32x4 cprev = creg[tm];     // still zero at a sentence's first step in this direction
-            f32x4 c, h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gi[tm][e] = sigmoidf_(pi[e]);
-                gf[tm][e] = sigmoidf_(pf[e]);
-                gg[tm][e] = tanhf_(pg[e]);
-                go[tm][e] = sigmoidf_(po[e]);
-                c[e] = gf[tm][e] * cprev[e] + gi[tm][e] * gg[tm][e];
-                h[e] = go[tm][e] * tanhf_(c[e]);
-            }
-            creg[tm] = c;
-            hp[tm] = pack_bf16x4(h);
-        }
-        {
-            // 16-byte sc1 stores (an 8-byte sc1 store is one fabric write of its own): lanes 16 apart
-            // hold neighbouring unit quads of the same sentence; after the row swap an even quad-row
-            // holds 8 consecutive units of row tm = 0, an odd one 8 consecutive units of row tm = 1.
-            static_assert(C::TM == 2, "publish pairs the wave's two row fragments");
-            const u32x4 v = lp_pair16(hp[0], hp[1]);
-            const int q = lane >> 4, tmq = q & 1;
-            if (tmq ? act[1] : act[0]) {
-                const long long row = ((long long)t * B + (tmq ? brow[1] : brow[0])) * 2 + dir;
-                lp_store16_sc1(&Hs[row * Hp + (col0 >> 6) * 16 + (q >> 1) * 8], v);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
-        ++done;
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-            if (!act[tm]) continue;
-            float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + col0 + u4;
-            *(f32x4*)(g + 0) = gi[tm];
-            *(f32x4*)(g + 16) = gf[tm];
-            *(f32x4*)(g + 32) = gg[tm];
-            *(f32x4*)(g + 48) = go[tm];
-            *(f32x4*)&Cs[(((long long)t * B + brow[tm]) * 2 + dir) * Hp + j] = creg[tm];
+// Bounded wait of ONE lane for `counter >= target`.  On a timeout the error word is raised and the
+// workgroup's LDS flag `dead` is set: from then on the workgroup stops waiting and publishes NaN
+// instead of results computed from stale hand-off data, so the failure reaches logits / loss / dS
+// (a NaN h or dZ propagates through every later product) instead of passing silently.
+__device__ __forceinline__ void lp_wait(gu32* counter, unsigned target, unsigned spin_limit, gu32* errword,
+                                        volatile unsigned* dead) {
+    if (*dead) return;
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > spin_limit) {
+            __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
+            *dead = 1u;
+            break;
         }
     }
 }
@@ -312,7 +121,7 @@ __global__ __launch_bounds__(512) void k_lstm_fwd_persist(Shape s, const int* __
 namespace sad {
 
 // ------------------------------------------------------------------------------------------------
-// K2b, second form: HALF-WIDTH workgroups, TWO per CU.
+// K2b: HALF-WIDTH workgroups, TWO per CU.
 // One step of the recurrence is a chain of waits (hand-off visible -> h loads -> MFMA -> cell update
 // -> write-through stores drained -> signal); with one workgroup per CU the CU idles through most of
 // it (13.4 us per step at cfg3 for 0.9 us of MFMA).  Here a workgroup has 256 threads and owns 128
@@ -325,7 +134,7 @@ namespace sad {
 //     parities, like dZ in the BPTT: the 16 lanes of a quarter wave read 256 contiguous bytes;
 //   * the row-major Hs (hidden bridge, weight gradients), the activated gates and c are written with
 //     plain stores after the signal.
-// Hand-off protocol: as in k_lstm_fwd_persist (16-byte sc1 stores, drain, barrier, counter add;
+// Hand-off protocol: the header of this file (16-byte sc1 stores, drain, barrier, counter add;
 // one-lane bounded poll, barrier, 16-byte sc1 loads).
 // ------------------------------------------------------------------------------------------------
 #ifndef SAD_LF_NS
@@ -355,10 +164,12 @@ __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int* __restrict__ lens,
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
-                                                          unsigned short* __restrict__ GA, unsigned* sync) {
+                                                          unsigned short* __restrict__ GA, unsigned* sync,
+                                                          unsigned spin_limit, int withhold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
     bf16raw* Wl = (bf16raw*)lp_lds;                          // [64][Hp], chunk-swizzled
+    if ((int)blockIdx.x == withhold) return;                 // test hook: this workgroup never signals
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctiles = Gp / LF_BN, rtiles = (B + LF_BM - 1) / LF_BM, groups = rtiles * 2;
     int group, ct;
@@ -383,9 +194,10 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
     }
     int maxlen = 0;
+    volatile unsigned* dead = (volatile unsigned*)(lp_lds + (size_t)LF_BN * Hp * 2 + 4);   // a wait timed out
     {
         int* red_max = (int*)(lp_lds + (size_t)LF_BN * Hp * 2);
-        if (tid == 0) *red_max = 0;
+        if (tid == 0) { *red_max = 0; *dead = 0u; }
         __syncthreads();
         if (tid < LF_BM && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
         __syncthreads();
@@ -407,7 +219,6 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     }
     const int nks = Hp / 32;
     unsigned done = 0;
-    bool dead = false;
     LF_PROF_DECL
 
     for (int step = 0; step < T; ++step) {
@@ -431,18 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
         LF_PROF_T(0)
         if (done > 0) {
-            if (tid == 0 && !dead) {
-                const unsigned target = done * (unsigned)ctiles;
-                unsigned spins = 0;
-                while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > LP_SPIN_LIMIT) {
-                        __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
-                        dead = true;
-                        break;
-                    }
-                }
-            }
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead);
             LF_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
             __syncthreads();
@@ -524,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
         // lanes 16 apart hold neighbouring unit quads of the same sentence: after the row swap an even
         // quad-row holds 8 consecutive units of row fragment 0, an odd one of row fragment 1
-        const u32x4 hv = lp_pair16(hp[0], hp[1]);
+        u32x4 hv = lp_pair16(hp[0], hp[1]);
+        if (*dead) hv = u32x4{LP_NAN2, LP_NAN2, LP_NAN2, LP_NAN2};   // timed out: never publish results of stale h
         const int tmq = q & 1;
         const bool actq = tmq ? act[1] : act[0];
         if (actq) lp_store16_sc1(HX + (done & 1) * xpar + (tmq ? xrow[1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u, hv);
@@ -573,7 +374,7 @@ namespace sad {
 // fragment sets in flight; there is no barrier inside the K loop, no cross-wave reduction (every
 // dh is summed by one wave in a fixed order: results are reproducible bit for bit), and the
 // accumulator layout (lane = sentence, 4 consecutive units) is exactly the epilogue's.
-// Hand-off protocol: as in k_lstm_fwd_persist.
+// Hand-off protocol: the header of this file, as in k_lstm_fwd_persist2.
 // ------------------------------------------------------------------------------------------------
 #ifndef SAD_LB_NS
 #define SAD_LB_NS 2
@@ -611,11 +412,13 @@ __host__ __device__ inline size_t lstm_bwd_xchg_bytes(int B, int Gp) {
 __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __restrict__ lens,
                                                          const bf16raw* __restrict__ whhT, const float* __restrict__ G,
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
-                                                         bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync) {
+                                                         bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync,
+                                                         unsigned spin_limit, int withhold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
     LB_PROF_ENTRY
     bf16raw* Wl = (bf16raw*)lp_lds;                                  // [32][Gp], chunk-swizzled
+    if ((int)blockIdx.x == withhold) return;                         // test hook: this workgroup never signals
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctiles = Hp / LB_BN, rtiles = (B + LB_BM - 1) / LB_BM, groups = rtiles * 2;
     int group, ct;
@@ -641,9 +444,10 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         }
     }
     int maxlen = 0;
+    volatile unsigned* dead = (volatile unsigned*)(lp_lds + (size_t)LB_BN * Gp * 2 + 4);   // a wait timed out
     {
         int* red_max = (int*)(lp_lds + (size_t)LB_BN * Gp * 2);
-        if (tid == 0) *red_max = 0;
+        if (tid == 0) { *red_max = 0; *dead = 0u; }
         __syncthreads();
         if (tid < LB_BM && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
         __syncthreads();
@@ -666,7 +470,6 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     const size_t xpar = (size_t)2 * sblocks * Gp * 16;       // elements of one parity
     const unsigned xrow = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave) * (Gp / 8) * 128 + (lane & 15) * 8);
     unsigned done = 0;
-    bool dead = false;
     int t_carry = -1;                                        // step whose c is held in eccarry (per lane)
     f32x4 eccarry[2];
     eccarry[0] = eccarry[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -713,18 +516,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         LB_PROF_T(0)
         if (done > 0) {
-            if (tid == 0 && !dead) {
-                const unsigned target = done * (unsigned)ctiles;
-                unsigned spins = 0;
-                while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > LP_SPIN_LIMIT) {
-                        __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
-                        dead = true;
-                        break;
-                    }
-                }
-            }
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead);
             LB_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();
@@ -801,6 +593,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         // swap an even quad-row holds 8 consecutive units of gate 2p, an odd one of gate 2p+1.  A wave's
         // store covers 4 consecutive chunks x 16 sentences = 1 KB of the hand-off image (sc1).
         u32x4 pv[2][2];
+        const bool poisoned = *dead != 0u;                   // timed out: never publish results of stale dZ
         {
             bf16raw* xout = DZX + (done & 1) * xpar + xrow;
             const int q = lane >> 4;
@@ -809,6 +602,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
                     pv[tn][p2] = lp_pair16(pk[tn][2 * p2], pk[tn][2 * p2 + 1]);
+                    if (poisoned) pv[tn][p2] = u32x4{LP_NAN2, LP_NAN2, LP_NAN2, LP_NAN2};
                     const int col = (pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8;
                     if (act) lp_store16_sc1(&xout[(col >> 3) * 128], pv[tn][p2]);
                 }

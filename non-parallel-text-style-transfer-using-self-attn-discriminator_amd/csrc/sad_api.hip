@@ -10,6 +10,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 using namespace sad;
 
 namespace {
@@ -31,6 +34,71 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- debug / test settings (sad_debug_set) ------------------------------------------------------
+std::atomic<int> g_no_persist{-1};                       // -1: not set -> SAD_NO_PERSIST of the environment, read once
+std::atomic<unsigned> g_spin_limit{LP_SPIN_LIMIT};       // bound of a hand-off wait inside the persistent recurrences
+std::atomic<int> g_withhold_fwd{-1}, g_withhold_bwd{-1}; // workgroup that exits at once (forces a hand-off timeout)
+
+bool no_persist() {
+    int v = g_no_persist.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* env = getenv("SAD_NO_PERSIST");
+        v = (env != nullptr && atoi(env) != 0) ? 1 : 0;
+        g_no_persist.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
+// ---- per-device facts, queried once (the occupancy / attribute calls cost microseconds each and the
+// step is ~1 ms; they used to run 4-6 times per forward + backward) --------------------------------
+std::mutex g_cache_mu;
+constexpr int MAX_DEVICES = 64;
+int g_cus[MAX_DEVICES];                                  // 0 = not queried yet
+struct KernelFacts {
+    int dev;
+    const void* kernel;
+    size_t lds;
+    int threads;
+    int per_cu;                                          // co-resident workgroups per CU at (threads, lds); -1 = query failed
+};
+constexpr int MAX_KERNEL_FACTS = 64;
+KernelFacts g_facts[MAX_KERNEL_FACTS];
+int g_nfacts = 0;
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 0;
+    return dev;
+}
+int device_cus() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (g_cus[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
+        g_cus[dev] = cus;
+    }
+    return g_cus[dev];
+}
+// Allows `lds` bytes of dynamic LDS for `kernel` on the current device (once) and returns how many of
+// its workgroups fit one CU.
+int kernel_per_cu(const void* kernel, size_t lds, int threads) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (int i = 0; i < g_nfacts; ++i)
+        if (g_facts[i].dev == dev && g_facts[i].kernel == kernel && g_facts[i].lds == lds && g_facts[i].threads == threads)
+            return g_facts[i].per_cu;
+    int per_cu = -1;
+    if (lds <= 65536 || hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) per_cu = -1;
+    }
+    (void)hipGetLastError();
+    if (g_nfacts < MAX_KERNEL_FACTS) g_facts[g_nfacts++] = KernelFacts{dev, kernel, lds, threads, per_cu};
+    return per_cu;
+}
+// Kernels with more than 64 KB of dynamic LDS: the limit has to be raised once per device.
+void allow_lds(const void* kernel, size_t lds, int threads) { (void)kernel_per_cu(kernel, lds, threads); }
 
 struct PackedLayout {
     size_t wembT, wemb, wcat, wcatT, bcat, whh, whhT, whb0, whb0T, bhb0, wq, wqT, bq, wa, ba, wo, bo, total;
@@ -185,61 +253,40 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const bf16raw* wembT = at<bf16raw>(packed, pl.wembT);
     bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
     float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
-    const bool wide = s.Ep > 128;
-    const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles (measured: B=64 166 -> 93 us, B=1024 302 -> 417 us)
-    static const bool fwd_ws = getenv("SAD_K1F_WS") == nullptr || atoi(getenv("SAD_K1F_WS")) != 0;   // A/B switch
-    static const int fwd_ws_kind = getenv("SAD_K1F_WS") == nullptr ? 4 : atoi(getenv("SAD_K1F_WS"));
-    if (fwd_ws && s.Ep == 320 && (!small_m || fwd_ws_kind >= 4) && s.V >= 64 && (kind == SAD_SRC_F32 || kind == SAD_SRC_BF16)) {
-        if (check_aligned(src, kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
-        const dim3 grid(ceil_div(s.M, 128));
-#define SAD_K1F_LAUNCH(KERNEL, LDS, THREADS)                                                                             \
-    {                                                                                                            \
-        static const hipError_t e_ = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-        (void)e_;                                                                                                \
-        hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), LDS, st, s, src, sT, sB, need, wembT, X);                    \
-    }
-        constexpr size_t lds2 = 2 * (128 * 128 + 320 * 128), lds3 = 2 * 128 * 128 + 3 * 320 * 128;
-        if (fwd_ws_kind >= 4) {     // stream-K over the non-empty row tiles: every CU gets an equal share
-            int* tiles = at<int>(ws, wl.off[SAD_WS_K1TILES]);
-            float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
-            int dev = 0, cus = 0;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const int nwg = cus < 1 ? 1 : (cus > K1_MAX_WGS ? K1_MAX_WGS : cus);
-            hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
-#define SAD_K1SK_LAUNCH(KERNEL)                                                                                   \
-    {                                                                                                             \
-        static const hipError_t e_ = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, lds3); \
-        (void)e_;                                                                                                 \
-        hipLaunchKernelGGL(KERNEL, dim3(nwg), dim3(1024), lds3, st, s, src, sT, sB, need, tiles, wembT, X, slabs); \
-    }
-            if (kind == SAD_SRC_F32) SAD_K1SK_LAUNCH(k_softemb_fwd_sk<SRC_F32>)
-            else SAD_K1SK_LAUNCH(k_softemb_fwd_sk<SRC_BF16>)
-#undef SAD_K1SK_LAUNCH
-            hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8, 4), dim3(64), 0, st, s, tiles, nwg, slabs, X);
-        } else if (fwd_ws_kind == 3) {     // S and W loader waves apart (deep S prefetch, LDS-direct W)
-            if (kind == SAD_SRC_F32) SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_F32>, lds3, 1024)
-            else SAD_K1F_LAUNCH(k_softemb_fwd_ws3<SRC_BF16>, lds3, 1024)
+    if (kind != SAD_SRC_F32 && kind != SAD_SRC_BF16)
+        return fail(-1, "soft-embedding stage needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
+    if (check_aligned(src, kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
+    if (s.Ep == 320 && s.V >= 64) {
+        // The shipped embedding size (E = 289..320): stream-K over the non-empty 128-row tiles, one
+        // workgroup per CU with an equal share of (tile, k-tile) units; three wave roles per workgroup.
+        constexpr size_t lds3 = 2 * 128 * 128 + 3 * 320 * 128;
+        int* tiles = at<int>(ws, wl.off[SAD_WS_K1TILES]);
+        float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
+        const int cus = device_cus();
+        const int nwg = cus > K1_MAX_WGS ? K1_MAX_WGS : cus;
+        hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
+        if (kind == SAD_SRC_F32) {
+            allow_lds((const void*)k_softemb_fwd_sk<SRC_F32>, lds3, 1024);
+            hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_F32>, dim3(nwg), dim3(1024), lds3, st, s, src, sT, sB, need, tiles, wembT, X, slabs);
         } else {
-            if (kind == SAD_SRC_F32) SAD_K1F_LAUNCH(k_softemb_fwd_ws<SRC_F32>, lds2, 768)
-            else SAD_K1F_LAUNCH(k_softemb_fwd_ws<SRC_BF16>, lds2, 768)
+            allow_lds((const void*)k_softemb_fwd_sk<SRC_BF16>, lds3, 1024);
+            hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_BF16>, dim3(nwg), dim3(1024), lds3, st, s, src, sT, sB, need, tiles, wembT, X, slabs);
         }
-#undef SAD_K1F_LAUNCH
-        SAD_CHECK_LAUNCH("k_softemb_fwd_ws");
+        hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8, 4), dim3(64), 0, st, s, tiles, nwg, slabs, X);
+        SAD_CHECK_LAUNCH("k_softemb_fwd_sk");
         return 0;
     }
+    // any other embedding size: the generic LDS-tiled kernel (split-K with fp32 atomics at small batches)
+    const bool wide = s.Ep > 128;
+    const bool small_m = s.M <= 16384;      // few row tiles: half-height tiles
     if (kind == SAD_SRC_F32) {
-        if (check_aligned(src, 4, "src")) return -1;
         if (wide && small_m) launch_softemb_fwd<CfgWideN64, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
         else if (wide) launch_softemb_fwd<CfgWideN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
         else launch_softemb_fwd<CfgNarrowN, SRC_F32>(s, src, sT, sB, need, wembT, X, accf, st);
-    } else if (kind == SAD_SRC_BF16) {
-        if (check_aligned(src, 2, "src")) return -1;
+    } else {
         if (wide && small_m) launch_softemb_fwd<CfgWideN64, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
         else if (wide) launch_softemb_fwd<CfgWideN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
         else launch_softemb_fwd<CfgNarrowN, SRC_BF16>(s, src, sT, sB, need, wembT, X, accf, st);
-    } else {
-        return fail(-1, "soft-embedding stage needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
     }
     SAD_CHECK_LAUNCH("k_softemb_fwd");
     return 0;
@@ -250,58 +297,32 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
     const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
     const bf16raw* wemb = at<bf16raw>(packed, pl.wemb);
     const bf16raw* DX = at<bf16raw>(ws, wl.off[SAD_WS_DX]);
-    // A-stationary fast path for the shipped embedding size (E = 300 -> Ep = 320 = 32*10)
-    const bool rs = s.Ep == 320;
-    const int mtiles = ceil_div(s.M, 256), ntiles = s.Vp / 64;
-    // One workgroup per CU is resident at a time (LDS), and every workgroup pays a prologue (dX
-    // fragments, first W tile): one round of ~256 workgroups (measured: 1024 -> 257 us, 256 -> 246 us).
-    static const int k1b_wgs = getenv("SAD_K1B_WGS") == nullptr ? 256 : atoi(getenv("SAD_K1B_WGS"));
-    int vsplit = k1b_wgs / mtiles;
-    vsplit = vsplit < 1 ? 1 : (vsplit > ntiles ? ntiles : vsplit);
-    const int nt_per = ceil_div(ntiles, vsplit);
-    const dim3 rs_grid(mtiles, ceil_div(ntiles, nt_per));
-    static const bool use_ws = getenv("SAD_K1B_WS") == nullptr || atoi(getenv("SAD_K1B_WS")) != 0;   // A/B switch
-    if (rs && use_ws) {
-        constexpr size_t lds = 2 * 64 * 10 * 64;
-        if (kind == SAD_SRC_F32) {
-            if (check_aligned(dsrc, 4, "dsrc")) return -1;
-            static const hipError_t e1 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws<10, SRC_F32>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)e1;
-            hipLaunchKernelGGL((k_softemb_bwd_ws<10, SRC_F32>), rs_grid, dim3(768), lds, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
-        } else if (kind == SAD_SRC_BF16) {
-            if (check_aligned(dsrc, 2, "dsrc")) return -1;
-            static const int ws_ver = getenv("SAD_K1B_WS") ? atoi(getenv("SAD_K1B_WS")) : 2;
-            if (ws_ver == 2) {      // loader + compute + store waves
-                constexpr size_t lds2 = 2 * 64 * 10 * 64 + 2 * 256 * 64 * 2;
-                static const hipError_t e3 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws2<10>,
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-                (void)e3;
-                hipLaunchKernelGGL((k_softemb_bwd_ws2<10>), rs_grid, dim3(768), lds2, st, s, DX, need, wemb, (bf16raw*)dsrc, sT, sB, nt_per);
-                SAD_CHECK_LAUNCH("k_softemb_bwd_ws2");
-                return 0;
-            }
-            static const hipError_t e2 = hipFuncSetAttribute((const void*)k_softemb_bwd_ws<10, SRC_BF16>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)e2;
-            hipLaunchKernelGGL((k_softemb_bwd_ws<10, SRC_BF16>), rs_grid, dim3(768), lds, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
-        } else {
-            return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
+    if (kind != SAD_SRC_F32 && kind != SAD_SRC_BF16)
+        return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
+    if (check_aligned(dsrc, kind == SAD_SRC_F32 ? 4 : 2, "dsrc")) return -1;
+    if (s.Ep == 320) {
+        // A-stationary fast path for the shipped embedding size (E = 289..320 -> Ep = 320 = 32*10).
+        // One workgroup per CU is resident at a time (LDS), and every workgroup pays a prologue (dX
+        // fragments, first W tile): one round of workgroups (measured: 1024 -> 257 us, 256 -> 246 us).
+        const int mtiles = ceil_div(s.M, 256), ntiles = s.Vp / 64;
+        int vsplit = device_cus() / mtiles;
+        vsplit = vsplit < 1 ? 1 : (vsplit > ntiles ? ntiles : vsplit);
+        const int nt_per = ceil_div(ntiles, vsplit);
+        const dim3 grid(mtiles, ceil_div(ntiles, nt_per));
+        if (kind == SAD_SRC_F32) {          // loader + compute waves
+            constexpr size_t lds = 2 * 64 * 10 * 64;
+            allow_lds((const void*)k_softemb_bwd_ws<10, SRC_F32>, lds, 768);
+            hipLaunchKernelGGL((k_softemb_bwd_ws<10, SRC_F32>), grid, dim3(768), lds, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
+        } else {                            // loader + compute + store waves
+            constexpr size_t lds2 = 2 * 64 * 10 * 64 + 2 * 256 * 64 * 2;
+            allow_lds((const void*)k_softemb_bwd_ws2<10>, lds2, 768);
+            hipLaunchKernelGGL((k_softemb_bwd_ws2<10>), grid, dim3(768), lds2, st, s, DX, need, wemb, (bf16raw*)dsrc, sT, sB, nt_per);
         }
         SAD_CHECK_LAUNCH("k_softemb_bwd_ws");
         return 0;
     }
-    if (kind == SAD_SRC_F32) {
-        if (check_aligned(dsrc, 4, "dsrc")) return -1;
-        if (rs) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_F32>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
-        else launch_softemb_bwd<CfgSquare, SRC_F32>(s, DX, need, wemb, dsrc, sT, sB, st);
-    } else if (kind == SAD_SRC_BF16) {
-        if (check_aligned(dsrc, 2, "dsrc")) return -1;
-        if (rs) hipLaunchKernelGGL((k_softemb_bwd_rs<10, SRC_BF16>), rs_grid, dim3(512), 0, st, s, DX, need, wemb, dsrc, sT, sB, nt_per);
-        else launch_softemb_bwd<CfgSquare, SRC_BF16>(s, DX, need, wemb, dsrc, sT, sB, st);
-    } else {
-        return fail(-1, "d(soft tokens) needs SAD_SRC_F32 or SAD_SRC_BF16, got %d", kind);
-    }
+    if (kind == SAD_SRC_F32) launch_softemb_bwd<CfgSquare, SRC_F32>(s, DX, need, wemb, dsrc, sT, sB, st);
+    else launch_softemb_bwd<CfgSquare, SRC_BF16>(s, DX, need, wemb, dsrc, sT, sB, st);
     SAD_CHECK_LAUNCH("k_softemb_bwd");
     return 0;
 }
@@ -316,36 +337,24 @@ int run_prep(const Shape& s, const WsLayout& wl, void* ws, const int32_t* length
 }
 
 // Weight-gradient kernels use two LDS tile buffers (up to 120 KB): dynamic LDS above the 64 KB
-// static limit has to be allowed once per kernel.
+// static limit has to be allowed once per kernel and device.
 template <class W, class K, class... Args>
 void launch_wg(K kernel, dim3 grid, hipStream_t st, Args... args) {
-    static const hipError_t attr =
-        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES);
-    (void)attr;
+    allow_lds((const void*)kernel, W::LDS_BYTES, W::NT);
     hipLaunchKernelGGL(kernel, grid, dim3(W::NT), W::LDS_BYTES, st, args...);
 }
 
 // The persistent recurrences need every workgroup co-resident (they wait for each other): the grid
-// must fit the device at the kernel's own occupancy.  SAD_NO_PERSIST=1 forces the per-step kernels.
-bool persist_fits(const void* kernel, size_t lds, int grid, int threads = 512) {
-    const char* env = getenv("SAD_NO_PERSIST");      // read per call: tests switch paths in-process
-    if (env != nullptr && atoi(env) != 0) return false;
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return false;
-    return per_cu >= 1 && grid <= per_cu * cus;
+// must fit the device at the kernel's own occupancy (queried once per device and LDS size).
+// sad_debug_set(SAD_DBG_NO_PERSIST, 1) / SAD_NO_PERSIST=1 force the per-step kernels.
+bool persist_fits(const void* kernel, size_t lds, int grid, int threads) {
+    if (no_persist()) return false;
+    const int per_cu = kernel_per_cu(kernel, lds, threads);
+    return per_cu >= 1 && grid <= per_cu * device_cus();
 }
-bool lstm_persist_fits(const Shape& s, int* grid) {
-    if (s.Hp > 64 * LP_KT_MAX || s.Gp % LP_BN != 0 || (long long)s.B * s.Hp * 4 >= (1ll << 31)) return false;
-    *grid = 2 * ceil_div(s.B, LP_BM) * (s.Gp / LP_BN);
-    return persist_fits((const void*)k_lstm_fwd_persist, lstm_persist_lds_bytes(s.Hp), *grid);
-}
-// half-width workgroups, two per CU (SAD_LSTM_FWD2=0 keeps the full-width kernel: A/B switch)
-bool lstm_persist2_fits(const Shape& s, int* grid) {
-    static const bool on = getenv("SAD_LSTM_FWD2") == nullptr || atoi(getenv("SAD_LSTM_FWD2")) != 0;
-    if (!on || s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
+// forward recurrence: half-width workgroups, two per CU
+bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
+    if (s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
     if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
     *grid = 2 * ceil_div(s.B, LF_BM) * (s.Gp / LF_BN);
     return persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256);
@@ -353,15 +362,14 @@ bool lstm_persist2_fits(const Shape& s, int* grid) {
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
     *grid = 2 * ceil_div(s.B, LB_BM) * (s.Hp / LB_BN);
-    return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid);
+    return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512);
 }
-// fp16 activated gates (SAD_WS_GA) are written by the half-width forward recurrence and read by the
-// persistent BPTT: used when both run (same decision in sad_forward and sad_backward; SAD_HALF_GATES=0
-// keeps fp32 gates in G).
+// fp16 activated gates (SAD_WS_GA) are written by the persistent forward recurrence and read by the
+// persistent BPTT: used when both run (same decision in sad_forward and sad_backward as long as the
+// debug settings do not change between the two calls).
 bool half_gates(const Shape& s) {
-    static const bool on = getenv("SAD_HALF_GATES") == nullptr || atoi(getenv("SAD_HALF_GATES")) != 0;
     int g1 = 0, g2 = 0;
-    return on && lstm_persist2_fits(s, &g1) && lstm_bwd_persist_fits(s, &g2);
+    return lstm_fwd_persist_fits(s, &g1) && lstm_bwd_persist_fits(s, &g2);
 }
 
 // sad_pack_weights collects its jobs here and launches them together (k_pack_all)
@@ -525,291 +533,394 @@ int sad_softemb_bwd(const sad_dims* d, const void* packed, void* dsrc, int32_t k
     return run_softemb_bwd(s, packed_layout(s), ws_layout(s), packed, workspace, dsrc, kind, sB, sT, (hipStream_t)stream);
 }
 
-int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* ws, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// ---- stages shared by sad_forward / sad_backward and the single-stage entry points -------------------
+struct Ctx {
     Shape s;
-    if (check_dims(d, &s)) return -1;
-    if (check_ptr(a, "args") || check_ptr(packed, "packed") || check_ptr(ws, "workspace") ||
-        check_aligned(ws, 256, "workspace") || check_aligned(packed, 256, "packed"))
+    PackedLayout pl;
+    WsLayout wl;
+    const void* packed;
+    void* ws;
+    hipStream_t st;
+};
+
+// K2a + K3: [G | Kk] = X . Wcat^T + bcat
+int run_inproj_fwd(const Ctx& c) {
+    const Shape& s = c.s;
+    const unsigned char* need = at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]);
+    const bf16raw* X = at<bf16raw>(c.ws, c.wl.off[SAD_WS_X]);
+    float* G = at<float>(c.ws, c.wl.off[SAD_WS_G]);
+    float* Kk = at<float>(c.ws, c.wl.off[SAD_WS_KK]);
+    if (s.Ep == 320 && s.Ncat % 64 == 0) {   // A-stationary + wave-private output turn (E = 289..320)
+        constexpr size_t lds = 2 * 64 * 10 * 64 + 8 * 8192;
+        allow_lds((const void*)k_inproj_fwd_rs2<10>, lds, 512);
+        const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
+        int nsplit = device_cus() / mtiles;      // one round of workgroups (measured: 8 -> 142 us, 2 -> 130 us)
+        nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+        const int nt_per = ceil_div(ntiles, nsplit);
+        hipLaunchKernelGGL((k_inproj_fwd_rs2<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(512), lds, c.st, s, X, need,
+                           at<bf16raw>(c.packed, c.pl.wcat), at<float>(c.packed, c.pl.bcat), G, Kk, nt_per);
+    } else {
+        typedef CfgSquare C;
+        dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
+        hipLaunchKernelGGL((k_inproj_fwd<C>), grid, dim3(C::NT), 0, c.st, s, X, need, at<bf16raw>(c.packed, c.pl.wcat),
+                           at<float>(c.packed, c.pl.bcat), G, Kk);
+    }
+    SAD_CHECK_LAUNCH("k_inproj_fwd");
+    return 0;
+}
+
+// K2b: the recurrence.  Persistent weight-stationary kernel (one launch for all T steps) when its grid
+// is co-resident, else T dependent launches (both directions per launch).  The hand-off counters and
+// the timeout words in SAD_WS_SYNC must be zero (k_prep of the same call, or run_zero_sync).
+int run_lstm_fwd(const Ctx& c) {
+    const Shape& s = c.s;
+    const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
+    float* G = at<float>(c.ws, c.wl.off[SAD_WS_G]);
+    float* Cs = at<float>(c.ws, c.wl.off[SAD_WS_CS]);
+    bf16raw* Hs = at<bf16raw>(c.ws, c.wl.off[SAD_WS_HS]);
+    const bf16raw* whh = at<bf16raw>(c.packed, c.pl.whh);
+    int pgrid = 0;
+    if (lstm_fwd_persist_fits(s, &pgrid)) {
+        hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), c.st, s, lens, whh, G, Cs,
+                           Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
+                           half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
+                           at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
+                           g_withhold_fwd.load(std::memory_order_relaxed));
+    } else {
+        for (int step = 0; step < s.T; ++step) {
+            if (s.B >= 512) {
+                typedef CfgStepBig C;
+                dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
+                hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, c.st, s, step, lens, whh, G, Cs, Hs, 0);
+            } else {
+                typedef CfgStepSmall C;
+                dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
+                hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, c.st, s, step, lens, whh, G, Cs, Hs, 0);
+            }
+        }
+    }
+    SAD_CHECK_LAUNCH("k_lstm_fwd");
+    return 0;
+}
+
+// K4: q = hidden_bridges[0]([h_fwd | h_rev]), u = linear_q(q)
+int run_bridge_fwd(const Ctx& c) {
+    const Shape& s = c.s;
+    const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
+    const bf16raw* Hs = at<bf16raw>(c.ws, c.wl.off[SAD_WS_HS]);
+    float* Q = at<float>(c.ws, c.wl.off[SAD_WS_Q]);
+    float* U = at<float>(c.ws, c.wl.off[SAD_WS_U]);
+    typedef CfgSmall C;
+    dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
+    hipLaunchKernelGGL((k_linear<C, 1>), grid, dim3(C::NT), 0, c.st, s, s.B, s.Hp, 2 * s.Hp, (const void*)Hs, 0, lens,
+                       at<bf16raw>(c.packed, c.pl.whb0), at<float>(c.packed, c.pl.bhb0), Q, s.Hp);
+    hipLaunchKernelGGL((k_linear<C, 0>), grid, dim3(C::NT), 0, c.st, s, s.B, s.Hp, s.Hp, (const void*)Q, s.Hp, lens,
+                       at<bf16raw>(c.packed, c.pl.wq), at<float>(c.packed, c.pl.bq), U, s.Hp);
+    SAD_CHECK_LAUNCH("k_linear");
+    return 0;
+}
+
+// K5: attention + pooling + head (+ CE)
+int run_attn_fwd(const Ctx& c, const int64_t* labels, float* logits, float* weights, float* loss) {
+    const Shape& s = c.s;
+    const unsigned char* need = at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]);
+    const float* Kk = at<float>(c.ws, c.wl.off[SAD_WS_KK]);
+    const float* U = at<float>(c.ws, c.wl.off[SAD_WS_U]);
+    float* CTX = at<float>(c.ws, c.wl.off[SAD_WS_CTX]);
+    const float* wa = at<float>(c.packed, c.pl.wa);
+    const float* ba = at<float>(c.packed, c.pl.ba);
+    const float* wo = at<float>(c.packed, c.pl.wo);
+    const float* bo = at<float>(c.packed, c.pl.bo);
+    const long long* lab = (const long long*)labels;
+    // timeout word of the forward recurrence (behind the hand-off counters)
+    const unsigned* err = at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]) + (size_t)2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH;
+#define SAD_ATT_FWD(NV)                                                                                             \
+    hipLaunchKernelGGL((k_attn_fwd<NV>), dim3(s.B), dim3(256), 0, c.st, s, Kk, U, need, wa, ba, wo, bo, lab, weights, CTX, \
+                       logits, loss, err)
+    if (s.Hp <= 256) SAD_ATT_FWD(1);
+    else if (s.Hp <= 512) SAD_ATT_FWD(2);
+    else if (s.Hp <= 1024) SAD_ATT_FWD(4);
+    else SAD_ATT_FWD(8);
+#undef SAD_ATT_FWD
+    SAD_CHECK_LAUNCH("k_attn_fwd");
+    return 0;
+}
+
+// K5': d logits -> dKk (key columns of DZ), du; zeroes the hand-off counters for the BPTT
+int run_attn_bwd(const Ctx& c, const sad_bwd_args* a) {
+    const Shape& s = c.s;
+    const float* Kk = at<float>(c.ws, c.wl.off[SAD_WS_KK]);
+    const float* U = at<float>(c.ws, c.wl.off[SAD_WS_U]);
+    const float* CTX = at<float>(c.ws, c.wl.off[SAD_WS_CTX]);
+    bf16raw* DZ = at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZ]);
+    float* DU = at<float>(c.ws, c.wl.off[SAD_WS_DU]);
+    const float* wa = at<float>(c.packed, c.pl.wa);
+    const float* wo = at<float>(c.packed, c.pl.wo);
+    const long long* lab = (const long long*)a->labels;
+#define SAD_ATT_BWD(NV)                                                                                              \
+    hipLaunchKernelGGL((k_attn_bwd<NV>), dim3(s.B), dim3(256), 0, c.st, s, Kk, U, wa, wo, a->weights, CTX, a->logits, \
+                       lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU,                                \
+                       at<float>(c.ws, c.wl.off[SAD_WS_DL]), at<float>(c.ws, c.wl.off[SAD_WS_DWA]),                   \
+                       at<float>(c.ws, c.wl.off[SAD_WS_DSSUM]), at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]),            \
+                       2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH)
+    if (s.Hp <= 256) SAD_ATT_BWD(1);
+    else if (s.Hp <= 512) SAD_ATT_BWD(2);
+    else if (s.Hp <= 1024) SAD_ATT_BWD(4);
+    else SAD_ATT_BWD(8);
+#undef SAD_ATT_BWD
+    SAD_CHECK_LAUNCH("k_attn_bwd");
+    return 0;
+}
+
+// K4': dq = du . W_q ; d[h_fwd | h_rev] = dq . W_hb0
+int run_bridge_bwd(const Ctx& c) {
+    const Shape& s = c.s;
+    const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
+    float* DU = at<float>(c.ws, c.wl.off[SAD_WS_DU]);
+    float* DQ = at<float>(c.ws, c.wl.off[SAD_WS_DQ]);
+    float* DHFIN = at<float>(c.ws, c.wl.off[SAD_WS_DHFIN]);
+    typedef CfgSmall C;
+    dim3 g1(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
+    hipLaunchKernelGGL((k_linear<C, 0>), g1, dim3(C::NT), 0, c.st, s, s.B, s.Hp, s.Hp, (const void*)DU, s.Hp, lens,
+                       at<bf16raw>(c.packed, c.pl.wqT), (const float*)nullptr, DQ, s.Hp);
+    dim3 g2(ceil_div(2 * s.Hp, C::BN), ceil_div(s.B, C::BM));
+    hipLaunchKernelGGL((k_linear<C, 0>), g2, dim3(C::NT), 0, c.st, s, s.B, 2 * s.Hp, s.Hp, (const void*)DQ, s.Hp, lens,
+                       at<bf16raw>(c.packed, c.pl.whb0T), (const float*)nullptr, DHFIN, 2 * s.Hp);
+    SAD_CHECK_LAUNCH("k_linear(bwd)");
+    return 0;
+}
+
+// K2': BPTT.  Persistent kernel (one launch) when its grid is co-resident, else T launches.  The
+// hand-off counters must be zero (k_attn_bwd of the same call, or run_zero_sync); the timeout words
+// behind them keep what the forward left.
+int run_lstm_bwd(const Ctx& c) {
+    const Shape& s = c.s;
+    const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
+    const float* G = at<float>(c.ws, c.wl.off[SAD_WS_G]);
+    const float* Cs = at<float>(c.ws, c.wl.off[SAD_WS_CS]);
+    const float* DHFIN = at<float>(c.ws, c.wl.off[SAD_WS_DHFIN]);
+    float* DC = at<float>(c.ws, c.wl.off[SAD_WS_DC]);
+    bf16raw* DZ = at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZ]);
+    const bf16raw* whhT = at<bf16raw>(c.packed, c.pl.whhT);
+    int pgrid = 0;
+    if (lstm_bwd_persist_fits(s, &pgrid)) {
+        hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), c.st, s, lens, whhT, G,
+                           Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
+                           half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr,
+                           at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
+                           g_withhold_bwd.load(std::memory_order_relaxed));
+    } else {
+        for (int step = 0; step < s.T; ++step) {
+            typedef CfgStepBwd C;
+            dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
+            hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, c.st, s, step, lens, whhT, G, Cs, DHFIN, DC, DZ);
+        }
+    }
+    SAD_CHECK_LAUNCH("k_lstm_bwd");
+    return 0;
+}
+
+// K2a' + K3': dX = dZ . Wcat
+int run_inproj_bwd(const Ctx& c) {
+    const Shape& s = c.s;
+    const unsigned char* need = at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]);
+    const bf16raw* DZ = at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZ]);
+    bf16raw* DX = at<bf16raw>(c.ws, c.wl.off[SAD_WS_DX]);
+    float* accf = at<float>(c.ws, c.wl.off[SAD_WS_ACCF]);
+    const bf16raw* wT = at<bf16raw>(c.packed, c.pl.wcatT);
+    if (s.Ep == 320 && s.Ncat % 64 == 0 && c.wl.bytes[SAD_WS_K1SLABS] != 0) {
+        // Ep = 320: the same GEMM shape as K1 (A = dZ rows, B = Wcat^T, K = Ncat), so it runs on K1's
+        // pipelined kernels with a patched shape.
+        Shape sp = s;
+        sp.V = s.Ncat;
+        sp.Vp = s.Ncat;
+        constexpr size_t lds3 = 2 * 128 * 128 + 3 * 320 * 128;
+        if (s.M < 16384) {       // few row tiles: stream-K fills the CUs (deterministic, no atomics)
+            int* tiles = at<int>(c.ws, c.wl.off[SAD_WS_K1TILES]);
+            float* slabs = at<float>(c.ws, c.wl.off[SAD_WS_K1SLABS]);
+            const int cus = device_cus();
+            const int nwg = cus > K1_MAX_WGS ? K1_MAX_WGS : cus;
+            hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, c.st, s.M, need, tiles);
+            allow_lds((const void*)k_softemb_fwd_sk<SRC_BF16>, lds3, 1024);
+            hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_BF16>, dim3(nwg), dim3(1024), lds3, c.st, sp, (const void*)DZ,
+                               (long long)s.B * s.Ncat, (long long)s.Ncat, need, tiles, wT, DX, slabs);
+            hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8, 4), dim3(64), 0, c.st, sp, tiles, nwg, slabs, DX);
+        } else {                 // three wave roles, one 128-row tile per workgroup (stream-K does not pay: 71 + 24 us vs 86)
+            allow_lds((const void*)k_softemb_fwd_ws3<SRC_BF16>, lds3, 1024);
+            hipLaunchKernelGGL(k_softemb_fwd_ws3<SRC_BF16>, dim3(ceil_div(s.M, 128)), dim3(1024), lds3, c.st, sp,
+                               (const void*)DZ, (long long)s.B * s.Ncat, (long long)s.Ncat, need, wT, DX);
+        }
+    } else {
+        const bool wide = s.Ep > 128;
+        const int bm = 128, bn = wide ? 320 : 64;
+        const int ksplit = split_k(ceil_div(s.M, bm) * ceil_div(s.Ep, bn), ceil_div(s.Ncat, 64));
+        dim3 grid(ceil_div(s.M, bm), ceil_div(s.Ep, bn), ksplit);
+        if (ksplit > 1) (void)hipMemsetAsync(accf, 0, (size_t)s.M * s.Ep * 4, c.st);
+        if (wide)
+            hipLaunchKernelGGL((k_inproj_bwd<CfgWideN>), grid, dim3(CfgWideN::NT), 0, c.st, s, DZ, need, wT, DX, accf, ksplit);
+        else
+            hipLaunchKernelGGL((k_inproj_bwd<CfgNarrowN>), grid, dim3(CfgNarrowN::NT), 0, c.st, s, DZ, need, wT, DX, accf, ksplit);
+        if (ksplit > 1) launch_cvt(accf, DX, (long long)s.M * s.Ep, c.st);
+    }
+    SAD_CHECK_LAUNCH("k_inproj_bwd");
+    return 0;
+}
+
+int run_apply_keep(const Ctx& c, bf16raw* x, const uint8_t* keep, float scale) {
+    const long long chunks = (long long)c.s.M * (c.s.Ep / 8);
+    int blocks = (int)((chunks + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_apply_keep, dim3(blocks), dim3(256), 0, c.st, c.s, x, keep, scale);
+    SAD_CHECK_LAUNCH("k_apply_keep");
+    return 0;
+}
+
+// Stage entry points run without the kernel that normally zeroes the hand-off counters in front of a
+// recurrence: a 256-byte-multiple memset on the same stream does it (counters only, or + timeout words).
+int run_zero_sync(const Ctx& c, bool with_timeout_words) {
+    const size_t counters = (size_t)2 * ceil_div(c.s.B, LP_BM) * LP_SYNC_PITCH * 4;
+    const size_t n = with_timeout_words ? c.wl.bytes[SAD_WS_SYNC] : counters;
+    if (hipMemsetAsync(at<unsigned char>(c.ws, c.wl.off[SAD_WS_SYNC]), 0, n, c.st) != hipSuccess)
+        return fail(-2, "hipMemsetAsync(SYNC) failed");
+    return 0;
+}
+
+int make_ctx(const sad_dims* d, const void* packed, void* ws, void* stream, Ctx* c) {
+    if (check_dims(d, &c->s)) return -1;
+    if (check_ptr(packed, "packed") || check_ptr(ws, "workspace") || check_aligned(ws, 256, "workspace") ||
+        check_aligned(packed, 256, "packed"))
         return -1;
+    c->pl = packed_layout(c->s);
+    c->wl = ws_layout(c->s);
+    c->packed = packed;
+    c->ws = ws;
+    c->st = (hipStream_t)stream;
+    return 0;
+}
+
+int forward_impl(const Ctx& c, const sad_fwd_args* a) {
+    const Shape& s = c.s;
+    if (check_ptr(a, "args")) return -1;
     if (check_ptr(a->src, "src") || check_ptr(a->lengths, "lengths") || check_ptr(a->mask, "mask") ||
         check_ptr(a->logits, "logits") || check_ptr(a->weights, "weights"))
         return -1;
     if (a->loss != nullptr && a->labels == nullptr) return fail(-1, "loss requested without labels");
-    hipStream_t st = (hipStream_t)stream;
-    const PackedLayout pl = packed_layout(s);
-    const WsLayout wl = ws_layout(s);
-    const int* lens = at<int>(ws, wl.off[SAD_WS_LENS]);
-    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
-    bf16raw* X = at<bf16raw>(ws, wl.off[SAD_WS_X]);
-    float* G = at<float>(ws, wl.off[SAD_WS_G]);
-    float* Cs = at<float>(ws, wl.off[SAD_WS_CS]);
-    bf16raw* Hs = at<bf16raw>(ws, wl.off[SAD_WS_HS]);
-    float* Kk = at<float>(ws, wl.off[SAD_WS_KK]);
-    float* Q = at<float>(ws, wl.off[SAD_WS_Q]);
-    float* U = at<float>(ws, wl.off[SAD_WS_U]);
-    float* CTX = at<float>(ws, wl.off[SAD_WS_CTX]);
-
-    int rc = run_prep(s, wl, ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, st);
+    bf16raw* X = at<bf16raw>(c.ws, c.wl.off[SAD_WS_X]);
+    // (k_prep also zeroes the hand-off counters and timeout words of the recurrence)
+    int rc = run_prep(s, c.wl, c.ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, c.st);
     if (rc) return rc;
-
     // K1 / gather
     if (a->src_kind == SAD_SRC_IDS) {
         if (check_aligned(a->src, 8, "src")) return -1;
         const long long chunks = (long long)s.M * (s.Ep / 8);
         int blocks = (int)((chunks + 255) / 256);
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_embed_gather, dim3(blocks), dim3(256), 0, st, s, (const long long*)a->src,
-                           (long long)a->src_stride_b, (long long)a->src_stride_t, at<bf16raw>(packed, pl.wemb), X);
+        hipLaunchKernelGGL(k_embed_gather, dim3(blocks), dim3(256), 0, c.st, s, (const long long*)a->src,
+                           (long long)a->src_stride_b, (long long)a->src_stride_t, at<bf16raw>(c.packed, c.pl.wemb), X);
         SAD_CHECK_LAUNCH("k_embed_gather");
     } else {
-        rc = run_softemb_fwd(s, pl, wl, packed, ws, a->src, a->src_kind, a->src_stride_b, a->src_stride_t, st);
+        rc = run_softemb_fwd(s, c.pl, c.wl, c.packed, c.ws, a->src, a->src_kind, a->src_stride_b, a->src_stride_t, c.st);
         if (rc) return rc;
     }
-
     // dropout on the embedded tokens (classifier copy, training mode)
-    if (a->drop_keep != nullptr) {
-        const long long chunks = (long long)s.M * (s.Ep / 8);
-        int blocks = (int)((chunks + 255) / 256);
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_apply_keep, dim3(blocks), dim3(256), 0, st, s, X, a->drop_keep, a->drop_scale);
-        SAD_CHECK_LAUNCH("k_apply_keep");
-    }
+    if (a->drop_keep != nullptr && (rc = run_apply_keep(c, X, a->drop_keep, a->drop_scale)) != 0) return rc;
+    if ((rc = run_inproj_fwd(c)) != 0) return rc;
+    if ((rc = run_lstm_fwd(c)) != 0) return rc;
+    if ((rc = run_bridge_fwd(c)) != 0) return rc;
+    return run_attn_fwd(c, a->labels, a->logits, a->weights, a->loss);
+}
 
-    // K2a + K3
-    {
-        static const int ipf_kind = getenv("SAD_INPROJ_FWD_WS") == nullptr ? 3 : atoi(getenv("SAD_INPROJ_FWD_WS"));
-        static const int ipf_split2 = getenv("SAD_INPROJ_FWD_SPLIT2") == nullptr ? 0 : atoi(getenv("SAD_INPROJ_FWD_SPLIT2"));
-        static const int ipf_split = getenv("SAD_INPROJ_FWD_SPLIT") == nullptr ? 8 : atoi(getenv("SAD_INPROJ_FWD_SPLIT"));
-        if (ipf_kind == 2 && s.Ep == 320 && s.Ncat % 64 == 0 && s.M > 16384) {   // + loader and store waves
-            constexpr size_t lds = 2 * (32 * 640) + 2 * (256 * 32 * 4);
-            static const hipError_t e_ = hipFuncSetAttribute((const void*)k_inproj_fwd_ws2<10>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)e_;
-            const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 32;
-            const int nsplit = ipf_split < 1 ? 1 : (ipf_split > ntiles ? ntiles : ipf_split);
-            const int nt_per = ceil_div(ntiles, nsplit);
-            hipLaunchKernelGGL((k_inproj_fwd_ws2<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(768), lds, st, s, X, need,
-                               at<bf16raw>(packed, pl.wcat), at<float>(packed, pl.bcat), G, Kk, nt_per);
-        } else if (ipf_kind == 3 && s.Ep == 320 && s.Ncat % 64 == 0) {   // A-stationary + wave-private output turn
-            constexpr size_t lds = 2 * 64 * 10 * 64 + 8 * 8192;
-            static const hipError_t e_ = hipFuncSetAttribute((const void*)k_inproj_fwd_rs2<10>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)e_;
-            const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
-            int nsplit = ipf_split2 > 0 ? ipf_split2 : 256 / mtiles;      // one round of workgroups (measured: 8 -> 142 us, 2 -> 130 us)
-            nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
-            const int nt_per = ceil_div(ntiles, nsplit);
-            hipLaunchKernelGGL((k_inproj_fwd_rs2<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(512), lds, st, s, X, need,
-                               at<bf16raw>(packed, pl.wcat), at<float>(packed, pl.bcat), G, Kk, nt_per);
-        } else if (s.Ep == 320 && s.Ncat % 64 == 0) {          // A-stationary fast path (E = 300)
-            const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
-            int nsplit = 1024 / mtiles;
-            nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
-            const int nt_per = ceil_div(ntiles, nsplit);
-            hipLaunchKernelGGL((k_inproj_fwd_rs<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(512), 0, st, s, X, need,
-                               at<bf16raw>(packed, pl.wcat), at<float>(packed, pl.bcat), G, Kk, nt_per);
-        } else {
-            typedef CfgSquare C;
-            dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
-            hipLaunchKernelGGL((k_inproj_fwd<C>), grid, dim3(C::NT), 0, st, s, X, need, at<bf16raw>(packed, pl.wcat),
-                               at<float>(packed, pl.bcat), G, Kk);
-        }
-        SAD_CHECK_LAUNCH("k_inproj_fwd");
-    }
-
-    // K2b: the recurrence.  Persistent weight-stationary kernel (one launch for all T steps) when its
-    // grid is co-resident, else T dependent launches (both directions per launch).
-    int pgrid = 0;
-    unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
-    // (counters + timeout words were zeroed by k_prep of this call)
-    if (lstm_persist2_fits(s, &pgrid)) {
-        hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), st, s, lens,
-                           at<bf16raw>(packed, pl.whh), G, Cs, Hs, at<bf16raw>(ws, wl.off[SAD_WS_HX]),
-                           half_gates(s) ? at<unsigned short>(ws, wl.off[SAD_WS_GA]) : (unsigned short*)nullptr, sync);
-    } else if (lstm_persist_fits(s, &pgrid)) {
-        hipLaunchKernelGGL(k_lstm_fwd_persist, dim3(pgrid), dim3(512), lstm_persist_lds_bytes(s.Hp), st, s, lens,
-                           at<bf16raw>(packed, pl.whh), G, Cs, Hs, sync);
-    } else {
-        for (int step = 0; step < s.T; ++step) {
-            if (s.B >= 512) {
-                typedef CfgStepBig C;
-                dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
-                hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, 0);
-            } else {
-                typedef CfgStepSmall C;
-                dim3 grid(ceil_div(s.Gp, C::BN), ceil_div(s.B, C::BM), 2);
-                hipLaunchKernelGGL((k_lstm_fwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whh), G, Cs, Hs, 0);
-            }
-        }
-    }
-    SAD_CHECK_LAUNCH("k_lstm_fwd");
-
-    // K4: q = hidden_bridges[0]([h_fwd | h_rev]), u = linear_q(q)
-    {
-        typedef CfgSmall C;
-        dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
-        hipLaunchKernelGGL((k_linear<C, 1>), grid, dim3(C::NT), 0, st, s, s.B, s.Hp, 2 * s.Hp, (const void*)Hs, 0, lens,
-                           at<bf16raw>(packed, pl.whb0), at<float>(packed, pl.bhb0), Q, s.Hp);
-        hipLaunchKernelGGL((k_linear<C, 0>), grid, dim3(C::NT), 0, st, s, s.B, s.Hp, s.Hp, (const void*)Q, s.Hp, lens,
-                           at<bf16raw>(packed, pl.wq), at<float>(packed, pl.bq), U, s.Hp);
-        SAD_CHECK_LAUNCH("k_linear");
-    }
-
-    // K5
-    {
-        const float* wa = at<float>(packed, pl.wa);
-        const float* ba = at<float>(packed, pl.ba);
-        const float* wo = at<float>(packed, pl.wo);
-        const float* bo = at<float>(packed, pl.bo);
-        const long long* lab = (const long long*)a->labels;
-#define SAD_ATT_FWD(NV)                                                                                              \
-    hipLaunchKernelGGL((k_attn_fwd<NV>), dim3(s.B), dim3(256), 0, st, s, Kk, U, need, wa, ba, wo, bo, lab, a->weights, \
-                       CTX, a->logits, a->loss)
-        if (s.Hp <= 256) SAD_ATT_FWD(1);
-        else if (s.Hp <= 512) SAD_ATT_FWD(2);
-        else if (s.Hp <= 1024) SAD_ATT_FWD(4);
-        else SAD_ATT_FWD(8);
-#undef SAD_ATT_FWD
-        SAD_CHECK_LAUNCH("k_attn_fwd");
-    }
+int check_bwd_args(const sad_bwd_args* a) {
+    if (check_ptr(a, "args")) return -1;
+    if (check_ptr(a->weights, "weights") || check_ptr(a->logits, "logits")) return -1;
+    if (a->dlogits == nullptr && a->labels == nullptr) return fail(-1, "need dlogits, or labels (+ dloss / dloss_scale)");
     return 0;
 }
 
-int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* ws, void* stream) {
-    Shape s;
-    if (check_dims(d, &s)) return -1;
-    if (check_ptr(a, "args") || check_ptr(packed, "packed") || check_ptr(ws, "workspace") ||
-        check_aligned(ws, 256, "workspace") || check_aligned(packed, 256, "packed"))
-        return -1;
-    if (check_ptr(a->weights, "weights") || check_ptr(a->logits, "logits")) return -1;
-    if (a->dlogits == nullptr && a->labels == nullptr) return fail(-1, "need dlogits, or labels (+ dloss / dloss_scale)");
-    hipStream_t st = (hipStream_t)stream;
-    const PackedLayout pl = packed_layout(s);
-    const WsLayout wl = ws_layout(s);
-    const int* lens = at<int>(ws, wl.off[SAD_WS_LENS]);
-    const unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
-    const float* G = at<float>(ws, wl.off[SAD_WS_G]);
-    const float* Cs = at<float>(ws, wl.off[SAD_WS_CS]);
-    const float* Kk = at<float>(ws, wl.off[SAD_WS_KK]);
-    const float* U = at<float>(ws, wl.off[SAD_WS_U]);
-    const float* CTX = at<float>(ws, wl.off[SAD_WS_CTX]);
-    bf16raw* DZ = at<bf16raw>(ws, wl.off[SAD_WS_DZ]);
-    bf16raw* DX = at<bf16raw>(ws, wl.off[SAD_WS_DX]);
-    float* DU = at<float>(ws, wl.off[SAD_WS_DU]);
-    float* DQ = at<float>(ws, wl.off[SAD_WS_DQ]);
-    float* DHFIN = at<float>(ws, wl.off[SAD_WS_DHFIN]);
-    float* DC = at<float>(ws, wl.off[SAD_WS_DC]);
+}  // namespace
 
-    // K5'
-    {
-        const float* wa = at<float>(packed, pl.wa);
-        const float* wo = at<float>(packed, pl.wo);
-        const long long* lab = (const long long*)a->labels;
-#define SAD_ATT_BWD(NV)                                                                                            \
-    hipLaunchKernelGGL((k_attn_bwd<NV>), dim3(s.B), dim3(256), 0, st, s, Kk, U, wa, wo, a->weights, CTX, a->logits, \
-                       lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU,                              \
-                       at<float>(ws, wl.off[SAD_WS_DL]), at<float>(ws, wl.off[SAD_WS_DWA]),                         \
-                       at<float>(ws, wl.off[SAD_WS_DSSUM]), at<unsigned>(ws, wl.off[SAD_WS_SYNC]),                  \
-                       2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH)
-        if (s.Hp <= 256) SAD_ATT_BWD(1);
-        else if (s.Hp <= 512) SAD_ATT_BWD(2);
-        else if (s.Hp <= 1024) SAD_ATT_BWD(4);
-        else SAD_ATT_BWD(8);
-#undef SAD_ATT_BWD
-        SAD_CHECK_LAUNCH("k_attn_bwd");
-    }
-    // K4': dq = du . W_q ; d[h_fwd | h_rev] = dq . W_hb0
-    {
-        typedef CfgSmall C;
-        dim3 g1(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
-        hipLaunchKernelGGL((k_linear<C, 0>), g1, dim3(C::NT), 0, st, s, s.B, s.Hp, s.Hp, (const void*)DU, s.Hp, lens,
-                           at<bf16raw>(packed, pl.wqT), (const float*)nullptr, DQ, s.Hp);
-        dim3 g2(ceil_div(2 * s.Hp, C::BN), ceil_div(s.B, C::BM));
-        hipLaunchKernelGGL((k_linear<C, 0>), g2, dim3(C::NT), 0, st, s, s.B, 2 * s.Hp, s.Hp, (const void*)DQ, s.Hp, lens,
-                           at<bf16raw>(packed, pl.whb0T), (const float*)nullptr, DHFIN, 2 * s.Hp);
-        SAD_CHECK_LAUNCH("k_linear(bwd)");
-    }
-    // K2': BPTT.  Persistent kernel (one launch) when its grid is co-resident, else T launches.
-    int pgrid = 0;
-    if (lstm_bwd_persist_fits(s, &pgrid)) {
-        unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
-        // counters only: the timeout words behind them keep what the forward left
-        // (zeroed by k_attn_bwd of this call)
-        hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), st, s, lens,
-                           at<bf16raw>(packed, pl.whhT), G, Cs, DHFIN, DZ, at<bf16raw>(ws, wl.off[SAD_WS_DZX]),
-                           half_gates(s) ? at<unsigned short>(ws, wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr, sync);
-    } else {
-        for (int step = 0; step < s.T; ++step) {
-            typedef CfgStepBwd C;
-            dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
-            hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, st, s, step, lens, at<bf16raw>(packed, pl.whhT), G, Cs,
-                               DHFIN, DC, DZ);
-        }
-    }
-    SAD_CHECK_LAUNCH("k_lstm_bwd");
-    // K2a' + K3'
-    {
-        float* accf = at<float>(ws, wl.off[SAD_WS_ACCF]);
-        const bool wide = s.Ep > 128;
-        // Large batches at Ep = 320: the same GEMM shape as K1 (A = dZ rows, B = Wcat^T, K = Ncat), so it
-        // runs on K1's pipelined kernels with a patched shape: 3 = three wave roles, 4 = + stream-K
-        // (SAD_INPROJ_BWD_WS=0: the single-role kernel; A/B switch).
-        static const int ws_kind = getenv("SAD_INPROJ_BWD_WS") == nullptr ? 3 : atoi(getenv("SAD_INPROJ_BWD_WS"));
-        if (ws_kind >= 3 && s.Ep == 320 && s.Ncat % 64 == 0 && wl.bytes[SAD_WS_K1SLABS] != 0) {
-            Shape sp = s;
-            sp.V = s.Ncat;
-            sp.Vp = s.Ncat;
-            constexpr size_t lds3 = 2 * 128 * 128 + 3 * 320 * 128;
-            const bf16raw* wT = at<bf16raw>(packed, pl.wcatT);
-            if (ws_kind >= 4 || s.M < 16384) {       // few row tiles: stream-K fills the CUs (deterministic, no atomics)
-                int* tiles = at<int>(ws, wl.off[SAD_WS_K1TILES]);
-                float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
-                int dev = 0, cus = 0;
-                (void)hipGetDevice(&dev);
-                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                const int nwg = cus < 1 ? 1 : (cus > K1_MAX_WGS ? K1_MAX_WGS : cus);
-                hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
-                static const hipError_t e_ = hipFuncSetAttribute((const void*)k_softemb_fwd_sk<SRC_BF16>,
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-                (void)e_;
-                hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_BF16>, dim3(nwg), dim3(1024), lds3, st, sp, (const void*)DZ,
-                                   (long long)s.B * s.Ncat, (long long)s.Ncat, need, tiles, wT, DX, slabs);
-                hipLaunchKernelGGL(k_softemb_fwd_fix, dim3(ceil_div(s.M, 128), 8, 4), dim3(64), 0, st, sp, tiles, nwg, slabs, DX);
-            } else {
-                static const hipError_t e_ = hipFuncSetAttribute((const void*)k_softemb_fwd_ws3<SRC_BF16>,
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-                (void)e_;
-                hipLaunchKernelGGL(k_softemb_fwd_ws3<SRC_BF16>, dim3(ceil_div(s.M, 128)), dim3(1024), lds3, st, sp,
-                                   (const void*)DZ, (long long)s.B * s.Ncat, (long long)s.Ncat, need, wT, DX);
-            }
-        } else {
-        const int bm = 128, bn = wide ? 320 : 64;
-        const int ksplit = split_k(ceil_div(s.M, bm) * ceil_div(s.Ep, bn), ceil_div(s.Ncat, 64));
-        dim3 grid(ceil_div(s.M, bm), ceil_div(s.Ep, bn), ksplit);
-        if (ksplit > 1) (void)hipMemsetAsync(accf, 0, (size_t)s.M * s.Ep * 4, st);
-        if (wide)
-            hipLaunchKernelGGL((k_inproj_bwd<CfgWideN>), grid, dim3(CfgWideN::NT), 0, st, s, DZ, need,
-                               at<bf16raw>(packed, pl.wcatT), DX, accf, ksplit);
-        else
-            hipLaunchKernelGGL((k_inproj_bwd<CfgNarrowN>), grid, dim3(CfgNarrowN::NT), 0, st, s, DZ, need,
-                               at<bf16raw>(packed, pl.wcatT), DX, accf, ksplit);
-        if (ksplit > 1) launch_cvt(accf, DX, (long long)s.M * s.Ep, st);
-        }
-    }
-    SAD_CHECK_LAUNCH("k_inproj_bwd");
-    if (a->drop_keep != nullptr) {      // d(embedded tokens) in front of the dropout
-        const long long chunks = (long long)s.M * (s.Ep / 8);
-        int blocks = (int)((chunks + 255) / 256);
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_apply_keep, dim3(blocks), dim3(256), 0, st, s, DX, a->drop_keep, a->drop_scale);
-        SAD_CHECK_LAUNCH("k_apply_keep");
-    }
+extern "C" {
+
+int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    return forward_impl(c, a);
+}
+
+int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    if (check_bwd_args(a)) return -1;
+    int rc;
+    if ((rc = run_attn_bwd(c, a)) != 0) return rc;
+    if ((rc = run_bridge_bwd(c)) != 0) return rc;
+    if ((rc = run_lstm_bwd(c)) != 0) return rc;
+    if ((rc = run_inproj_bwd(c)) != 0) return rc;
+    // d(embedded tokens) in front of the dropout
+    if (a->drop_keep != nullptr &&
+        (rc = run_apply_keep(c, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DX]), a->drop_keep, a->drop_scale)) != 0)
+        return rc;
     // K1'
-    if (a->dsrc != nullptr) {
-        int rc = run_softemb_bwd(s, pl, wl, packed, ws, a->dsrc, a->dsrc_kind, a->dsrc_stride_b, a->dsrc_stride_t, st);
-        if (rc) return rc;
-    }
+    if (a->dsrc != nullptr)
+        return run_softemb_bwd(c.s, c.pl, c.wl, packed, ws, a->dsrc, a->dsrc_kind, a->dsrc_stride_b, a->dsrc_stride_t, c.st);
     return 0;
+}
+
+// ---- single stages (unit tests, timing the kernel classes in isolation) ---------------------------
+int sad_lstm_fwd(const sad_dims* d, const void* packed, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    int rc = run_zero_sync(c, true);
+    return rc ? rc : run_lstm_fwd(c);
+}
+
+int sad_lstm_bwd(const sad_dims* d, const void* packed, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    int rc = run_zero_sync(c, false);
+    return rc ? rc : run_lstm_bwd(c);
+}
+
+int sad_inproj_fwd(const sad_dims* d, const void* packed, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    return run_inproj_fwd(c);
+}
+
+int sad_inproj_bwd(const sad_dims* d, const void* packed, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    return run_inproj_bwd(c);
+}
+
+int sad_attnpool_fwd(const sad_dims* d, const void* packed, const int64_t* labels, float* logits, float* weights,
+                     float* loss, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    if (check_ptr(logits, "logits") || check_ptr(weights, "weights")) return -1;
+    if (loss != nullptr && labels == nullptr) return fail(-1, "loss requested without labels");
+    return run_attn_fwd(c, labels, logits, weights, loss);
+}
+
+int sad_attnpool_bwd(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* ws, void* stream) {
+    Ctx c;
+    if (make_ctx(d, packed, ws, stream, &c)) return -1;
+    if (check_bwd_args(a)) return -1;
+    return run_attn_bwd(c, a);
+}
+
+int sad_debug_set(int32_t key, int64_t value) {
+    switch (key) {
+        case SAD_DBG_NO_PERSIST: g_no_persist.store(value != 0 ? 1 : 0); return 0;
+        case SAD_DBG_SPIN_LIMIT: g_spin_limit.store(value <= 0 ? LP_SPIN_LIMIT : (unsigned)value); return 0;
+        case SAD_DBG_WITHHOLD_FWD: g_withhold_fwd.store((int)value); return 0;
+        case SAD_DBG_WITHHOLD_BWD: g_withhold_bwd.store((int)value); return 0;
+        default: return fail(-1, "unknown debug key %d", key);
+    }
 }
 
 int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, const void* src, int32_t src_kind,

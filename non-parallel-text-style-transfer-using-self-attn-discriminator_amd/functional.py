@@ -128,6 +128,25 @@ class Workspace:
         off, nb = _lib.workspace_field(self.d, name)
         return self.buf[off:off + nb].view(dtype)
 
+    def handoff_timeouts(self):
+        """(forward, backward) timeout words of the persistent recurrences.  SYNCHRONISES (reads device
+        memory): call it where a sync happens anyway (tests, benchmarks, a logging interval)."""
+        words = self.view("SYNC", torch.int32)[-32:-30].tolist()
+        return int(words[0]), int(words[1])
+
+    def check(self):
+        """Raise RuntimeError if a hand-off wait inside a persistent recurrence timed out during the
+        calls that used this workspace (the outputs of such a call are NaN by construction; this gives
+        the reason).  The usual cause: the recurrence's workgroups were not all resident because another
+        kernel occupied CUs of the device (another stream or process, CU masking)."""
+        f, b = self.handoff_timeouts()
+        if f or b:
+            raise RuntimeError(
+                "libsad: a hand-off wait inside the persistent LSTM %s timed out — its workgroups were not "
+                "co-resident (another kernel running on the device?). logits / loss / d(soft tokens) of this "
+                "call are NaN. Run nothing else on the device during the discriminator step, or set "
+                "SAD_NO_PERSIST=1." % ("forward recurrence" if f else "BPTT"))
+
 
 def _src_kind(src):
     if src.dim() == 2:
@@ -184,6 +203,11 @@ def _grad_struct(views):
 
 
 _N_FIXED = 8   # forward() arguments in front of *params
+
+# Debug / profiling hook (tests, bench.py, tools): when True the last call's Workspace and flat
+# gradient bucket stay reachable as _Discriminator.last_workspace / .last_grad_bucket.  Off by
+# default: the hook would keep one full workspace alive for the life of the process.
+KEEP_LAST = False
 
 
 class _Discriminator(torch.autograd.Function):
@@ -244,18 +268,24 @@ class _Discriminator(torch.autograd.Function):
         any_param = any(ctx.needs_input_grad[_N_FIXED:])
         if kind == _lib.SRC_IDS and not any_param:
             ctx.mark_non_differentiable(*([logits, weights] + ([loss] if loss is not None else [])))
-        # the forward input is needed again for d embedding.weight (S^T . dX / scatter-add by id)
+        # Outputs and inputs go through save_for_backward: kept on ctx directly they would close a
+        # cycle output -> grad_fn -> ctx -> output that Python's GC cannot see (the grad_fn is held by
+        # C++ shared_ptrs of every output), and each call would leak its whole workspace.
+        # The forward input is needed again for d embedding.weight (S^T . dX / scatter-add by id).
         keep_src = src if (params and ctx.needs_input_grad[_N_FIXED]) else None
-        ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype, labels, logits, weights, keep_src,
+        ctx.save_for_backward(logits, weights, labels, keep_src)
+        ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype,
                    -1 if pad_id is None else int(pad_id), [tuple(p.shape) for p in params], drop)
-        _Discriminator.last_workspace = ws   # introspection hook for tests / profiling
+        if KEEP_LAST:
+            _Discriminator.last_workspace = ws   # introspection hook for tests / profiling
         if loss is None:
             return logits, weights
         return logits, weights, loss
 
     @staticmethod
     def backward(ctx, dlogits, dweights, dloss=None):
-        d, ws, pw, kind, shape, strides, dtype, labels, logits, weights, src, pad_id, pshapes, drop = ctx.sad
+        d, ws, pw, kind, shape, strides, dtype, pad_id, pshapes, drop = ctx.sad
+        logits, weights, labels, src = ctx.saved_tensors
         n_out = _N_FIXED + len(pshapes)
         want_src = kind != _lib.SRC_IDS and ctx.needs_input_grad[0]
         want_p = [bool(x) for x in ctx.needs_input_grad[_N_FIXED:]]
@@ -263,11 +293,7 @@ class _Discriminator(torch.autograd.Function):
             return (None,) * n_out
         dev = logits.device
         B = shape[0]
-        if dlogits is not None and dloss is not None:
-            p = torch.softmax(logits, dim=1)
-            p[torch.arange(B, device=dev), labels] -= 1.0
-            dlogits = dlogits + p * dloss.unsqueeze(1)
-            dloss = None
+        # (dlogits and dloss may both arrive: k_attn_bwd adds the CE term to the given dlogits)
         if dlogits is None and dloss is None:
             if dweights is None:
                 return (None,) * n_out
@@ -318,7 +344,8 @@ class _Discriminator(torch.autograd.Function):
                 sb, st_ = (strides[0], strides[1])
                 _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d), ctypes.byref(g), sp, kind, sb, st_, pad_id,
                                                           _ptr(ws.buf), _stream_ptr()), "sad_param_grads_accumulate")
-                _Discriminator.last_grad_bucket = flat
+                if KEEP_LAST:
+                    _Discriminator.last_grad_bucket = flat
         del keep
         return (dsrc, None, None, None, None, None, None, None) + tuple(pgrads)
 
@@ -440,7 +467,9 @@ class _SoftEmbedding(torch.autograd.Function):
             _lib.check(lib.sad_softemb_fwd(ctypes.byref(d), _ptr(pw.buf), _ptr(Sv), kind, Sv.stride(1), Sv.stride(0),
                                            _ptr(ws.buf), _stream_ptr()), "sad_softemb_fwd")
         Ep = _lib.padded_dims(d)["Ep"]
-        X = ws.view("X", torch.bfloat16)[:T * B * Ep].view(T, B, Ep)[:, :, :E].to(S.dtype)
+        # always a COPY out of the shared per-shape workspace (a bf16 `.to()` would be a view that the next
+        # call of the same shape overwrites)
+        X = ws.view("X", torch.bfloat16)[:T * B * Ep].view(T, B, Ep)[:, :, :E].to(S.dtype, copy=True)
         ctx.save_for_backward(Sv, weight)
         ctx.meta = (d, ws, pw, kind, swap, lead, Ep)
         out = X.transpose(0, 1) if swap else X

@@ -20,7 +20,10 @@ WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", 
 # every symbol include/sad.h declares (tests/test_cabi.py checks the .so exports all of them)
 EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",
            "sad_workspace_bytes", "sad_workspace_field", "sad_pack_weights", "sad_forward",
-           "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd", "sad_uses_half_gates")
+           "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd", "sad_uses_half_gates",
+           "sad_inproj_fwd", "sad_inproj_bwd", "sad_lstm_fwd", "sad_lstm_bwd", "sad_attnpool_fwd", "sad_attnpool_bwd", "sad_debug_set")
+
+DBG_NO_PERSIST, DBG_SPIN_LIMIT, DBG_WITHHOLD_FWD, DBG_WITHHOLD_BWD = 0, 1, 2, 3
 
 
 class SadDims(ctypes.Structure):
@@ -103,6 +106,13 @@ def load():
     lib.sad_prep.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]
     lib.sad_softemb_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]
     lib.sad_softemb_bwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p]
+    lib.sad_lstm_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_void_p]
+    lib.sad_inproj_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_void_p]
+    lib.sad_inproj_bwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_void_p]
+    lib.sad_lstm_bwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_void_p]
+    lib.sad_attnpool_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.sad_attnpool_bwd.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadBwdArgs), c_void_p, c_void_p]
+    lib.sad_debug_set.argtypes = [c_int32, c_int64]
     for name in EXPORTS:
         getattr(lib, name)   # AttributeError here = header/library drift
     _lib = lib
@@ -118,6 +128,11 @@ def check(rc, what):
     (reference classifier/trainers.py:375-382 special-cases 'out of memory' in the message)."""
     if rc != 0:
         raise RuntimeError("libsad %s failed (%d): %s" % (what, rc, last_error()))
+
+
+def debug_set(key, value):
+    """Process-wide test / diagnosis settings of the library (include/sad.h, sad_debug_set)."""
+    check(load().sad_debug_set(int(key), int(value)), "sad_debug_set")
 
 
 def dims(B, T, V, E, H, L):

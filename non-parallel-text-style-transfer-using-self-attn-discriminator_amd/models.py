@@ -103,12 +103,28 @@ class _SelfAttnBase(nn.Module):
         return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard, params=self._trainable(),
                                 pad_id=self.embedding.padding_idx, drop=drop)
 
+    def _draw_keep(self, src):
+        """Inverted-dropout keep mask on the embedded tokens [T,B,E] (classifier copy in training mode,
+        reference classifier/models.py:126,217): drawn with torch's generator (plumbing), applied by the
+        kernels in the forward and in the backward.  None for the transfer copy / eval mode / p = 0."""
+        if self._flavour != "classifier" or not self.training or self.dropout_p <= 0.0:
+            return None
+        B, T = src.shape[0], src.shape[1]
+        keep = torch.rand((T, B, self.embedding.embedding_dim), device=src.device) >= self.dropout_p
+        return keep, 1.0 / (1.0 - self.dropout_p)
+
     def loss(self, src, src_len, mask, labels, soft=True):
         """Fused variant: per-sentence CE vs ``labels`` computed inside the attention kernels
-        (reference transfer/models.py:1185-1212). Returns (loss [B], logits, weights)."""
+        (reference transfer/models.py:1185-1212). Returns (loss [B], logits, weights).  ``mask`` is the
+        pad+sos+eos mask (both flavours); the classifier flavour applies the same training-mode dropout
+        as its ``forward``."""
+        if soft and src.dim() != 3:
+            raise RuntimeError("soft=True expects [B,T,V] soft tokens")
+        if not soft and src.dim() != 2:
+            raise RuntimeError("soft=False expects [B,T] token ids")
         return Fn.discriminator_loss(src, src_len, mask, labels, self.packed_weights(),
                                      guard=self._flavour == "transfer", params=self._trainable(),
-                                     pad_id=self.embedding.padding_idx)
+                                     pad_id=self.embedding.padding_idx, drop=self._draw_keep(src))
 
 
 class TransferSelfAttnRNNClassifier(_SelfAttnBase):
@@ -133,13 +149,7 @@ class ClassifierSelfAttnRNNClassifier(_SelfAttnBase):
         return torch.cat([ones, pad_mask[:, 2:], ones], dim=1)
 
     def forward(self, src, src_len, pad_mask=None, hidden=None, soft=False):
-        drop = None
-        if self.training and self.dropout_p > 0.0:
-            # dropout on the embedded tokens [T,B,E] (classifier/models.py:217): the mask is drawn here with
-            # torch's generator (plumbing), the kernels apply it in the forward and in the backward
-            B, T = src.shape[0], src.shape[1]
-            keep = torch.rand((T, B, self.embedding.embedding_dim), device=src.device) >= self.dropout_p
-            drop = (keep, 1.0 / (1.0 - self.dropout_p))
+        drop = self._draw_keep(src)
         if pad_mask is None:
             mask = torch.zeros(src.shape[:2], dtype=torch.bool, device=src.device)
         else:

@@ -77,6 +77,23 @@ def make_lengths(B, T, seed=0, lo=3, full=False):
     return np.sort(ln)[::-1].astype(np.int32).copy()
 
 
+# Sentence lengths (tokens + sos + eos) of the reference's data/yelp/dev.0 + dev.1, 4000 sentences:
+# length -> count.  Data, counted in the build container with
+#   collections.Counter(len(line.split()) + 2 for f in ("dev.0", "dev.1") for line in open(f))
+# ("cfg2 ... lengths from real dev.* (+2 for sos/eos; observed min 3, mean 10.9, max 17)").
+YELP_DEV_LENGTH_COUNTS = {3: 12, 4: 90, 5: 195, 6: 227, 7: 340, 8: 348, 9: 323, 10: 320, 11: 324, 12: 346, 13: 327,
+                          14: 313, 15: 284, 16: 278, 17: 273}
+
+
+def yelp_dev_lengths(B, T, seed=0):
+    """B sentence lengths drawn from the Yelp dev length histogram (clipped to T), sorted descending."""
+    ks = np.array(sorted(YELP_DEV_LENGTH_COUNTS), dtype=np.int64)
+    pr = np.array([YELP_DEV_LENGTH_COUNTS[k] for k in ks], dtype=np.float64)
+    rs = np.random.RandomState(seed + 611953)
+    ln = np.minimum(rs.choice(ks, size=B, p=pr / pr.sum()), T)
+    return np.sort(ln)[::-1].astype(np.int32).copy()
+
+
 def transfer_mask(lengths, T):
     """pad/sos/eos mask exactly as the transfer step builds it for soft outputs
     (reference transfer/models.py:1180-1183): ``arange(T) >= len-1`` and column 0 set."""

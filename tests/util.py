@@ -55,6 +55,7 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
     Returns dict of numpy arrays (logits, weights, loss, mask_after, dS [B,T,V], ws fields)."""
     import torch
     from sad_amd import functional as Fn
+    Fn.KEEP_LAST = True           # debug hook: keep the call's workspace reachable for inspection
     dev = torch.device("cuda:0")
     tp = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in params.items()}
     pw = Fn.pack_weights(tp)
@@ -104,8 +105,7 @@ def run_sad(params, src, lengths, mask, labels=None, soft=True, s_dtype="f32", t
         if param_grads:
             out["grads"] = {k: (None if v.grad is None else v.grad.cpu().numpy()) for k, v in live.items()}
     torch.cuda.synchronize()
-    # hand-off counters of the persistent recurrence: the word after them is set when a wait timed out
-    assert int(ws.view("SYNC", torch.int32)[-32]) == 0, "persistent LSTM: a hand-off wait timed out"
+    ws.check()                    # raises if a hand-off wait of the persistent recurrences timed out
     out.update(logits=logits.detach().cpu().numpy(), weights=weights.detach().cpu().numpy(),
                loss=None if loss is None else loss.detach().cpu().numpy(), mask_after=m.cpu().numpy())
     if want_ws:

@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sad_amd import functional as Fn, synth
+Fn.KEEP_LAST = True
 import bench
 dev = torch.device("cuda:0")
 w = dict(bench.WORKLOADS["cfg3"])

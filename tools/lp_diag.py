@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sad_amd import functional as Fn, synth
+Fn.KEEP_LAST = True
 dev = torch.device("cuda:0")
 B, T, V, E, H = 1024, 32, 500, 300, 512
 lengths = synth.make_lengths(B, T, seed=B)

@@ -186,6 +186,17 @@ int sad_pack_weights(const sad_dims* d, const sad_weights* w, void* packed, void
  * Saves what the backward needs in `workspace`. */
 int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* workspace, void* stream);
 
+/* sad_forward without a workspace argument and without any allocation.  It has NO counterpart in the
+ * reference; it exists for callers that cannot allocate device memory around the call: code under HIP
+ * graph capture, tight serving loops that score hard tokens (calls #1 / #3 of the transfer step,
+ * reference transfer/models.py:1065-1074, 1233-1262), harnesses that forbid hipMalloc.  The workspace is
+ * a static device array of SAD_NOALLOC_MAX_BYTES inside the library (each GPU the library runs on holds
+ * it until the process ends); shapes whose sad_workspace_bytes() exceeds it are refused (-3) with a
+ * message.  Calls on one GPU share that array: calls that overlap on one GPU (two streams, two host
+ * threads) race — serialise them.  Forward only: nothing is saved for a sad_backward. */
+#define SAD_NOALLOC_MAX_BYTES (192u << 20)
+int sad_forward_noalloc(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* stream);
+
 /* Autograd backward of the above down to d(soft tokens) with frozen parameters — what
  * loss.backward() (reference transfer/trainers.py:376) runs through transfer/models.py:1185-1187.
  * `workspace` must be the one the matching sad_forward filled. */

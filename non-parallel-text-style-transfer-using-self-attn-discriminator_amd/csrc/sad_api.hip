@@ -15,6 +15,11 @@
 
 using namespace sad;
 
+// Workspace of sad_forward_noalloc: lives in the code object, one copy per GPU the library is loaded
+// on, never freed.  Host code must not use this name as an address (it is a host-side stand-in):
+// noalloc_scratch() resolves the device address once per device with hipGetSymbolAddress.
+static __device__ __align__(256) unsigned char g_noalloc_scratch[SAD_NOALLOC_MAX_BYTES];
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -802,6 +807,22 @@ int make_ctx(const sad_dims* d, const void* packed, void* ws, void* stream, Ctx*
     return 0;
 }
 
+// Device address of g_noalloc_scratch on the current device, resolved on the first call per device.
+unsigned char* g_noalloc_ptr[MAX_DEVICES];
+int noalloc_scratch(unsigned char** out) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (g_noalloc_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+        if (e != hipSuccess || p == nullptr)
+            return fail(-2, "hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+        g_noalloc_ptr[dev] = (unsigned char*)p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return 0;
+}
+
 int forward_impl(const Ctx& c, const sad_fwd_args* a) {
     const Shape& s = c.s;
     if (check_ptr(a, "args")) return -1;
@@ -868,6 +889,21 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     if (a->dsrc != nullptr)
         return run_softemb_bwd(c.s, c.pl, c.wl, packed, ws, a->dsrc, a->dsrc_kind, a->dsrc_stride_b, a->dsrc_stride_t, c.st);
     return 0;
+}
+
+int sad_forward_noalloc(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* stream) {
+    Shape s;
+    if (check_dims(d, &s)) return -1;
+    const size_t need = ws_layout(s).total;
+    if (need > (size_t)SAD_NOALLOC_MAX_BYTES)
+        return fail(-3, "sad_forward_noalloc: B=%d T=%d V=%d E=%d H=%d needs a workspace of %zu bytes, the static scratch "
+                        "holds %zu (use sad_forward with a caller-provided workspace)",
+                    d->B, d->T, d->V, d->E, d->H, need, (size_t)SAD_NOALLOC_MAX_BYTES);
+    unsigned char* scratch = nullptr;
+    if (noalloc_scratch(&scratch)) return -2;
+    Ctx c;
+    if (make_ctx(d, packed, scratch, stream, &c)) return -1;
+    return forward_impl(c, a);
 }
 
 // ---- single stages (unit tests, timing the kernel classes in isolation) ---------------------------

@@ -21,7 +21,7 @@ WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", 
 EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",
            "sad_workspace_bytes", "sad_workspace_field", "sad_pack_weights", "sad_forward",
            "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd", "sad_uses_half_gates",
-           "sad_inproj_fwd", "sad_inproj_bwd", "sad_lstm_fwd", "sad_lstm_bwd", "sad_attnpool_fwd", "sad_attnpool_bwd", "sad_debug_set")
+           "sad_inproj_fwd", "sad_inproj_bwd", "sad_lstm_fwd", "sad_lstm_bwd", "sad_attnpool_fwd", "sad_attnpool_bwd", "sad_debug_set", "sad_forward_noalloc")
 
 DBG_NO_PERSIST, DBG_SPIN_LIMIT, DBG_WITHHOLD_FWD, DBG_WITHHOLD_BWD = 0, 1, 2, 3
 
@@ -99,6 +99,7 @@ def load():
     lib.sad_pack_weights.argtypes = [POINTER(SadDims), POINTER(SadWeights), c_void_p, c_void_p]
     lib.sad_forward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadFwdArgs), c_void_p, c_void_p]
     lib.sad_backward.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadBwdArgs), c_void_p, c_void_p]
+    lib.sad_forward_noalloc.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadFwdArgs), c_void_p]
     lib.sad_param_grads_accumulate.argtypes = [POINTER(SadDims), POINTER(SadParamGrads), c_void_p, c_int32, c_int64,
                                                c_int64, c_int32, c_void_p, c_void_p]
     lib.sad_uses_half_gates.argtypes = [POINTER(SadDims)]

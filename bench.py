@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--api", default="fused", choices=["fused", "module"])
     ap.add_argument("--s-dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--onehot", action="store_true",
+                    help="straight-through one-hot soft tokens (what the transfer loop really emits) with the "
+                         "(index, value) side channel of the fused producer: K1 forward becomes a gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table (counter passes)")
     a = ap.parse_args()
@@ -270,8 +273,15 @@ def main():
         w["B"] = hi - lo
     else:
         S, lengths, ln_dev, mask, labels = make_inputs(w, 1234 + rank, dev, yelp_lengths=a.workload == "yelp64")
-    Sv = S.transpose(0, 1).requires_grad_(True)           # [B,T,V] view, exactly like the transfer loop
     B, T, V = w["B"], w["T"], w["V"]
+    onehot = None
+    if a.onehot:
+        # exact one-hot rows + their side channel, as producer.SoftTokenAssembler emits them
+        ids_tb = torch.from_numpy(synth.make_token_ids(B, T, V, lengths, seed=1234 + rank)).to(dev).t().contiguous()   # [T,B]
+        S.zero_()
+        S.scatter_(2, ids_tb.unsqueeze(2), 1.0)
+        onehot = (ids_tb.t(), torch.ones((T, B), dtype=torch.float32, device=dev).t())
+    Sv = S.transpose(0, 1).requires_grad_(True)           # [B,T,V] view, exactly like the transfer loop
 
     if a.api == "module":
         # the drop-in module as reference transfer/models.py:1172-1212 drives it: CPU int16 lengths,
@@ -291,14 +301,14 @@ def main():
 
         def step():
             Sv.grad = None
-            logits, _ = model(Sv, len16, mask.clone(), soft=True)
+            logits, _ = model(Sv, len16, mask.clone(), soft=True, onehot=onehot)
             loss = torch.nn.functional.cross_entropy(logits, inv_lab, reduction="none")
             (loss.sum() / global_B).backward()
             return loss
     else:
         def step():
             Sv.grad = None
-            loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
+            loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, onehot=onehot)
             (loss.sum() / global_B).backward()
             return loss
 
@@ -384,10 +394,10 @@ def main():
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s: synthetic Yelp-shaped soft tokens, B=%d per GPU, T=%d, V=%d, E=%d, H=%d, "
-                                   "len %s sorted, S %s, frozen discriminator (no param grads, no collective), api=%s"
+                                   "len %s sorted, S %s%s, frozen discriminator (no param grads, no collective), api=%s"
                                    % (a.workload, B, T, V, w["E"], w["H"],
                                       "from data/yelp/dev.* (+sos/eos)" if a.workload == "yelp64" else "~U{3..T}",
-                                      w["s_dtype"], a.api),
+                                      w["s_dtype"], " straight-through one-hot + side channel" if a.onehot else " dense", a.api),
                        "global_batch": units, "seq_len": T, "parallelism": "dp%d" % world,
                        "mfma_inputs": "bf16", "accumulate": "fp32"},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

@@ -83,6 +83,16 @@ typedef struct sad_fwd_args {
                                  tokens, X *= keep * drop_scale (classifier copy in training mode, reference
                                  classifier/models.py:217; the caller draws the mask) */
     float drop_scale;         /* 1 / (1 - p) */
+    /* Optional one-hot side channel of soft tokens (what sad_gumbel_st_step /
+     * sad_soft_finalize emit): when `src` holds straight-through one-hot rows (reference
+     * transfer/models.py:531, hard=True) the caller may pass, per token, the index of the non-zero entry
+     * and its value; K1 forward then gathers X = value * W_emb[index] instead of contracting the row with the
+     * whole embedding matrix — bit-identical to the GEMM on such rows.  `src` is still required (parameter
+     * gradients read it) and d(soft tokens) stays dense.  NULL = no side channel. */
+    const int64_t* onehot_ids;  /* [B,T] through the strides below */
+    const float* onehot_val;    /* [B,T] */
+    int64_t onehot_stride_b;
+    int64_t onehot_stride_t;
 } sad_fwd_args;
 
 typedef struct sad_bwd_args {
@@ -247,6 +257,47 @@ int sad_lstm_bwd(const sad_dims* d, const void* packed, void* workspace, void* s
 int sad_attnpool_fwd(const sad_dims* d, const void* packed, const int64_t* labels, float* logits, float* weights,
                      float* loss, void* workspace, void* stream);
 int sad_attnpool_bwd(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* workspace, void* stream);
+
+/* ---- fused producer of the soft tokens ---------------------------------------------
+ * One decode step of AttnRNNDecoder.soft_decode (reference transfer/models.py:531-543): the straight-through
+ * Gumbel-softmax sample  y_hard - y_soft + y_soft,  y_soft = softmax((logits + noise) / tau),  written
+ * straight into its row of the time-major soft-token tensor in the dtype the discriminator consumes, plus
+ * the (index, value) side channel and the alive / length bookkeeping.  The caller draws `noise`
+ * (-log(Exp(1)), as F.gumbel_softmax does) with its own generator. */
+typedef struct sad_gumbel_args {
+    int32_t B, V;
+    const float* logits;      /* [B,V], row stride logits_stride */
+    int64_t logits_stride;
+    const float* noise;       /* [B,V] Gumbel(0,1) samples, row stride noise_stride */
+    int64_t noise_stride;
+    float tau;
+    const uint8_t* alive;     /* [B] soft_decode's `mask` before this step (1 = still decoding), NULL = all */
+    int32_t eos_id;
+    void* s_row;              /* out: row t of S for every sentence: sample * alive */
+    int32_t s_kind;           /* SAD_SRC_F32 / SAD_SRC_BF16 */
+    int64_t s_stride_b;       /* element stride between sentences inside that row (V for dense time-major S) */
+    float* rnn_in;            /* out [B,V] fp32: the un-masked sample (next decoder input), or NULL */
+    float* y_soft;            /* out [B,V] fp32: saved for the backward, or NULL */
+    int64_t* idx;             /* out [B]: arg-max index */
+    float* val;               /* out [B]: value at the arg-max times alive */
+    int32_t* lens;            /* in/out [B] or NULL: += alive        (outputs_len += mask, :542) */
+    uint8_t* alive_out;       /* out [B] or NULL: alive && idx != eos (:543); may alias `alive` */
+} sad_gumbel_args;
+int sad_gumbel_st_step(const sad_gumbel_args* a, void* stream);
+/* Its autograd: dlogits = y_soft * (g - <g, y_soft>) / tau with g = alive * d s_row (+ d rnn_in); either
+ * gradient source may be NULL. */
+int sad_gumbel_st_step_bwd(int32_t B, int32_t V, const void* d_s_row, int32_t s_kind, int64_t s_stride_b,
+                           const float* d_rnn_in, const uint8_t* alive, const float* y_soft, float tau,
+                           float* dlogits, int64_t dlogits_stride, void* stream);
+/* After the last step (reference transfer/models.py:546-571, 1180-1183): [sos] row 0, an [eos] row for
+ * sentences still alive when the length limit stopped the loop (`over_max`), one-hot [pad] for t >= len, the
+ * side channel of those rows, final lengths and the pad+sos+eos mask.  S is [T][B][V] through element
+ * strides; `steps` decode steps filled rows 1..steps; T = steps + 1, + 1 if a sentence gets the [eos] row
+ * (over_max and still alive: the caller knows from the loop's own `any(alive)` test). */
+int sad_soft_finalize(int32_t B, int32_t T, int32_t V, int32_t steps, int32_t over_max, int32_t pad_id, int32_t sos_id,
+                      int32_t eos_id, void* S, int32_t s_kind, int64_t s_stride_t, int64_t s_stride_b, int64_t* ids,
+                      float* val, const int32_t* lens_steps, const uint8_t* alive, int32_t* lens_out, uint8_t* mask,
+                      void* stream);
 
 /* Test / diagnosis settings (process-wide; no counterpart in the reference).  Do not change them
  * between a sad_forward and its sad_backward.

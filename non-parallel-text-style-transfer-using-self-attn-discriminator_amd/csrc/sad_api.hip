@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "wgrad.hpp"
 #include "lstm_persist.hpp"
+#include "producer.hpp"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -843,6 +844,18 @@ int forward_impl(const Ctx& c, const sad_fwd_args* a) {
         hipLaunchKernelGGL(k_embed_gather, dim3(blocks), dim3(256), 0, c.st, s, (const long long*)a->src,
                            (long long)a->src_stride_b, (long long)a->src_stride_t, at<bf16raw>(c.packed, c.pl.wemb), X);
         SAD_CHECK_LAUNCH("k_embed_gather");
+    } else if (a->onehot_ids != nullptr) {
+        // one-hot soft tokens with their (index, value) side channel: K1 forward is a scaled gather
+        if (a->src_kind != SAD_SRC_F32 && a->src_kind != SAD_SRC_BF16)
+            return fail(-1, "soft tokens need SAD_SRC_F32 or SAD_SRC_BF16, got %d", a->src_kind);
+        if (check_ptr(a->onehot_val, "onehot_val") || check_aligned(a->onehot_ids, 8, "onehot_ids")) return -1;
+        const long long chunks = (long long)s.M * (s.Ep / 8);
+        int blocks = (int)((chunks + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_embed_gather_scaled, dim3(blocks), dim3(256), 0, c.st, s, (const long long*)a->onehot_ids,
+                           (long long)a->onehot_stride_b, (long long)a->onehot_stride_t, a->onehot_val,
+                           (long long)a->onehot_stride_b, (long long)a->onehot_stride_t, at<bf16raw>(c.packed, c.pl.wemb), X);
+        SAD_CHECK_LAUNCH("k_embed_gather_scaled");
     } else {
         rc = run_softemb_fwd(s, c.pl, c.wl, c.packed, c.ws, a->src, a->src_kind, a->src_stride_b, a->src_stride_t, c.st);
         if (rc) return rc;
@@ -947,6 +960,66 @@ int sad_attnpool_bwd(const sad_dims* d, const void* packed, const sad_bwd_args* 
     if (make_ctx(d, packed, ws, stream, &c)) return -1;
     if (check_bwd_args(a)) return -1;
     return run_attn_bwd(c, a);
+}
+
+int sad_gumbel_st_step(const sad_gumbel_args* a, void* stream) {
+    if (check_ptr(a, "args")) return -1;
+    if (a->B < 1 || a->V < 1) return fail(-1, "B and V must be positive (B=%d V=%d)", a->B, a->V);
+    if (check_ptr(a->logits, "logits") || check_ptr(a->noise, "noise") || check_ptr(a->s_row, "s_row") ||
+        check_ptr(a->idx, "idx") || check_ptr(a->val, "val"))
+        return -1;
+    if (!(a->tau > 0.f)) return fail(-1, "tau must be positive");
+    hipStream_t st = (hipStream_t)stream;
+#define SAD_GUMBEL(KIND)                                                                                              \
+    hipLaunchKernelGGL((k_gumbel_st_fwd<KIND>), dim3(a->B), dim3(256), 0, st, a->B, a->V, a->logits,                   \
+                       (long long)a->logits_stride, a->noise, (long long)a->noise_stride, a->tau, a->alive, a->eos_id, \
+                       a->s_row, (long long)a->s_stride_b, a->rnn_in, a->y_soft, (long long*)a->idx, a->val, a->lens,  \
+                       a->alive_out)
+    if (a->s_kind == SAD_SRC_F32) SAD_GUMBEL(SRC_F32);
+    else if (a->s_kind == SAD_SRC_BF16) SAD_GUMBEL(SRC_BF16);
+    else return fail(-1, "s_kind must be SAD_SRC_F32 or SAD_SRC_BF16, got %d", a->s_kind);
+#undef SAD_GUMBEL
+    SAD_CHECK_LAUNCH("k_gumbel_st_fwd");
+    return 0;
+}
+
+int sad_gumbel_st_step_bwd(int32_t B, int32_t V, const void* d_s_row, int32_t s_kind, int64_t s_stride_b,
+                           const float* d_rnn_in, const uint8_t* alive, const float* y_soft, float tau, float* dlogits,
+                           int64_t dlogits_stride, void* stream) {
+    if (B < 1 || V < 1) return fail(-1, "B and V must be positive (B=%d V=%d)", B, V);
+    if (check_ptr(y_soft, "y_soft") || check_ptr(dlogits, "dlogits")) return -1;
+    if (d_s_row == nullptr && d_rnn_in == nullptr) return fail(-1, "need d_s_row or d_rnn_in");
+    hipStream_t st = (hipStream_t)stream;
+    if (s_kind == SAD_SRC_F32)
+        hipLaunchKernelGGL((k_gumbel_st_bwd<SRC_F32>), dim3(B), dim3(256), 0, st, B, V, d_s_row, (long long)s_stride_b, d_rnn_in,
+                           alive, y_soft, tau, dlogits, (long long)dlogits_stride);
+    else if (s_kind == SAD_SRC_BF16)
+        hipLaunchKernelGGL((k_gumbel_st_bwd<SRC_BF16>), dim3(B), dim3(256), 0, st, B, V, d_s_row, (long long)s_stride_b, d_rnn_in,
+                           alive, y_soft, tau, dlogits, (long long)dlogits_stride);
+    else return fail(-1, "s_kind must be SAD_SRC_F32 or SAD_SRC_BF16, got %d", s_kind);
+    SAD_CHECK_LAUNCH("k_gumbel_st_bwd");
+    return 0;
+}
+
+int sad_soft_finalize(int32_t B, int32_t T, int32_t V, int32_t steps, int32_t over_max, int32_t pad_id, int32_t sos_id,
+                      int32_t eos_id, void* S, int32_t s_kind, int64_t sT, int64_t sB, int64_t* ids, float* val,
+                      const int32_t* lens_steps, const uint8_t* alive, int32_t* lens_out, uint8_t* mask, void* stream) {
+    if (B < 1 || V < 1 || T < 1 || steps < 0) return fail(-1, "bad sizes (B=%d T=%d V=%d steps=%d)", B, T, V, steps);
+    if (T < steps + 1) return fail(-1, "T=%d is too small for %d steps + [sos]", T, steps);
+    if (B > 65535) return fail(-1, "B too large for this entry point");
+    if (check_ptr(S, "S") || check_ptr(ids, "ids") || check_ptr(val, "val") || check_ptr(lens_steps, "lens_steps") ||
+        check_ptr(alive, "alive") || check_ptr(lens_out, "lens_out") || check_ptr(mask, "mask"))
+        return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (s_kind == SAD_SRC_F32)
+        hipLaunchKernelGGL((k_soft_finalize<SRC_F32>), dim3(T, B), dim3(256), 0, st, B, T, V, steps, over_max, pad_id, sos_id, eos_id, S,
+                           (long long)sT, (long long)sB, (long long*)ids, val, lens_steps, alive, lens_out, mask);
+    else if (s_kind == SAD_SRC_BF16)
+        hipLaunchKernelGGL((k_soft_finalize<SRC_BF16>), dim3(T, B), dim3(256), 0, st, B, T, V, steps, over_max, pad_id, sos_id, eos_id, S,
+                           (long long)sT, (long long)sB, (long long*)ids, val, lens_steps, alive, lens_out, mask);
+    else return fail(-1, "s_kind must be SAD_SRC_F32 or SAD_SRC_BF16, got %d", s_kind);
+    SAD_CHECK_LAUNCH("k_soft_finalize");
+    return 0;
 }
 
 int sad_debug_set(int32_t key, int64_t value) {

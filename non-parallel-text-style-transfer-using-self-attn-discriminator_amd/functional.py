@@ -202,7 +202,7 @@ def _grad_struct(views):
     return g
 
 
-_N_FIXED = 8   # forward() arguments in front of *params
+_N_FIXED = 9   # forward() arguments in front of *params
 
 # Debug / profiling hook (tests, bench.py, tools): when True the last call's Workspace and flat
 # gradient bucket stay reachable as _Discriminator.last_workspace / .last_grad_bucket.  Off by
@@ -211,7 +211,10 @@ KEEP_LAST = False
 
 
 class _Discriminator(torch.autograd.Function):
-    """forward(src, lengths, mask, labels, pw, guard, pad_id, drop, *params).
+    """forward(src, lengths, mask, labels, pw, guard, pad_id, drop, onehot, *params).
+
+    ``onehot`` is None or (ids int64 [B,T], val float32 [B,T]) — the side channel of straight-through
+    one-hot soft tokens (producer.SoftTokenAssembler): K1 forward gathers instead of contracting.
 
     ``drop`` is None or (keep [T,B,E] bool/uint8 CUDA tensor, scale): inverted dropout on the embedded
     tokens with the caller's mask (classifier copy in training mode, reference classifier/models.py:217).
@@ -222,7 +225,7 @@ class _Discriminator(torch.autograd.Function):
     classifier/trainers.py:367-373)."""
 
     @staticmethod
-    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, drop, *params):
+    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, drop, onehot, *params):
         if not src.is_cuda:
             raise RuntimeError("sad_amd runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
         if params and len(params) != len(_LIVE_PARAMS):
@@ -261,6 +264,15 @@ class _Discriminator(torch.autograd.Function):
                 raise RuntimeError("dropout keep mask must be [T,B,E] = %s, got %s" % ((T, B, pw.E), tuple(keep.shape)))
             a.drop_keep, a.drop_scale = keep.data_ptr(), float(scale)
             drop = (keep, float(scale))
+        if onehot is not None:
+            if kind == _lib.SRC_IDS:
+                raise RuntimeError("the one-hot side channel belongs to soft tokens, not to token ids")
+            oh_ids, oh_val = onehot
+            if (oh_ids.dtype != torch.int64 or oh_val.dtype != torch.float32 or tuple(oh_ids.shape) != (B, T)
+                    or tuple(oh_val.shape) != (B, T) or oh_ids.stride() != oh_val.stride() or oh_ids.device != dev):
+                raise RuntimeError("onehot = (ids int64 [B,T], val float32 [B,T]) with equal strides on the device of src")
+            a.onehot_ids, a.onehot_val = oh_ids.data_ptr(), oh_val.data_ptr()
+            a.onehot_stride_b, a.onehot_stride_t = oh_ids.stride(0), oh_ids.stride(1)
         with torch.cuda.device(dev):
             _lib.check(_lib.load().sad_forward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
                                                _stream_ptr()), "sad_forward")
@@ -347,7 +359,7 @@ class _Discriminator(torch.autograd.Function):
                 if KEEP_LAST:
                     _Discriminator.last_grad_bucket = flat
         del keep
-        return (dsrc, None, None, None, None, None, None, None) + tuple(pgrads)
+        return (dsrc,) + (None,) * (_N_FIXED - 1) + tuple(pgrads)
 
 
 def _live(params):
@@ -357,20 +369,21 @@ def _live(params):
     return tuple(params[n] for n in _LIVE_PARAMS)
 
 
-def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None, drop=None):
+def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None, drop=None, onehot=None):
     """(logits [B,L], attention weights [B,T]) — the reference module's return value.
 
     ``params`` (name -> nn.Parameter, optional) makes the call differentiable w.r.t. the parameters
     that require grad; without it the discriminator is frozen (gradient flows to soft tokens only)."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, drop, *_live(params))
+    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, drop, onehot, *_live(params))
 
 
-def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None, drop=None):
+def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None, drop=None, onehot=None):
     """(per-sentence CE loss [B], logits, weights) with the cross entropy fused into the attention
     kernels — what the transfer step computes at reference transfer/models.py:1185-1212."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, drop, *_live(params))
+    logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, drop, onehot,
+                                                 *_live(params))
     return loss, logits, weights
 
 

@@ -21,7 +21,8 @@ WS_FIELDS = ("LENS", "NEED", "X", "G", "CS", "HS", "KK", "Q", "U", "CTX", "DZ", 
 EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes",
            "sad_workspace_bytes", "sad_workspace_field", "sad_pack_weights", "sad_forward",
            "sad_backward", "sad_param_grads_accumulate", "sad_prep", "sad_softemb_fwd", "sad_softemb_bwd", "sad_uses_half_gates",
-           "sad_inproj_fwd", "sad_inproj_bwd", "sad_lstm_fwd", "sad_lstm_bwd", "sad_attnpool_fwd", "sad_attnpool_bwd", "sad_debug_set", "sad_forward_noalloc")
+           "sad_inproj_fwd", "sad_inproj_bwd", "sad_lstm_fwd", "sad_lstm_bwd", "sad_attnpool_fwd", "sad_attnpool_bwd", "sad_debug_set", "sad_forward_noalloc",
+           "sad_gumbel_st_step", "sad_gumbel_st_step_bwd", "sad_soft_finalize")
 
 DBG_NO_PERSIST, DBG_SPIN_LIMIT, DBG_WITHHOLD_FWD, DBG_WITHHOLD_BWD = 0, 1, 2, 3
 
@@ -62,6 +63,18 @@ class SadFwdArgs(ctypes.Structure):
         ("labels", c_void_p),
         ("logits", c_void_p), ("weights", c_void_p), ("loss", c_void_p),
         ("drop_keep", c_void_p), ("drop_scale", c_float),
+        ("onehot_ids", c_void_p), ("onehot_val", c_void_p), ("onehot_stride_b", c_int64), ("onehot_stride_t", c_int64),
+    ]
+
+
+class SadGumbelArgs(ctypes.Structure):
+    _fields_ = [
+        ("B", c_int32), ("V", c_int32),
+        ("logits", c_void_p), ("logits_stride", c_int64), ("noise", c_void_p), ("noise_stride", c_int64),
+        ("tau", c_float), ("alive", c_void_p), ("eos_id", c_int32),
+        ("s_row", c_void_p), ("s_kind", c_int32), ("s_stride_b", c_int64),
+        ("rnn_in", c_void_p), ("y_soft", c_void_p), ("idx", c_void_p), ("val", c_void_p),
+        ("lens", c_void_p), ("alive_out", c_void_p),
     ]
 
 
@@ -114,6 +127,10 @@ def load():
     lib.sad_attnpool_fwd.argtypes = [POINTER(SadDims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.sad_attnpool_bwd.argtypes = [POINTER(SadDims), c_void_p, POINTER(SadBwdArgs), c_void_p, c_void_p]
     lib.sad_debug_set.argtypes = [c_int32, c_int64]
+    lib.sad_gumbel_st_step.argtypes = [POINTER(SadGumbelArgs), c_void_p]
+    lib.sad_gumbel_st_step_bwd.argtypes = [c_int32, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_float,
+                                           c_void_p, c_int64, c_void_p]
+    lib.sad_soft_finalize.argtypes = [c_int32] * 8 + [c_void_p, c_int32, c_int64, c_int64] + [c_void_p] * 7
     for name in EXPORTS:
         getattr(lib, name)   # AttributeError here = header/library drift
     _lib = lib

@@ -93,7 +93,7 @@ class _SelfAttnBase(nn.Module):
             return live
         return None
 
-    def _run(self, src, src_len, mask, hidden, soft, guard, drop=None):
+    def _run(self, src, src_len, mask, hidden, soft, guard, drop=None, onehot=None):
         if hidden is not None:
             raise NotImplementedError("an initial hidden state is never passed by the reference callers")
         if soft and src.dim() != 3:
@@ -101,7 +101,7 @@ class _SelfAttnBase(nn.Module):
         if not soft and src.dim() != 2:
             raise RuntimeError("soft=False expects [B,T] token ids")
         return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard, params=self._trainable(),
-                                pad_id=self.embedding.padding_idx, drop=drop)
+                                pad_id=self.embedding.padding_idx, drop=drop, onehot=onehot)
 
     def _draw_keep(self, src):
         """Inverted-dropout keep mask on the embedded tokens [T,B,E] (classifier copy in training mode,
@@ -131,8 +131,10 @@ class TransferSelfAttnRNNClassifier(_SelfAttnBase):
     """Reference transfer/models.py:753-953."""
     _flavour = "transfer"
 
-    def forward(self, src, src_len, pad_sos_eos_mask, hidden=None, soft=False):
-        return self._run(src, src_len, pad_sos_eos_mask, hidden, soft, guard=True)
+    def forward(self, src, src_len, pad_sos_eos_mask, hidden=None, soft=False, onehot=None):
+        """``onehot`` (optional, not in the reference): (ids, val) side channel of straight-through one-hot
+        soft tokens from producer.SoftTokenAssembler — the soft-embedding contraction becomes a gather."""
+        return self._run(src, src_len, pad_sos_eos_mask, hidden, soft, guard=True, onehot=onehot)
 
 
 class ClassifierSelfAttnRNNClassifier(_SelfAttnBase):

@@ -2044,6 +2044,75 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* 
     });
 }
 
+// K2a + K3 over the COMPACTED list of needed token rows (k_row_lists, list 0), work split evenly:
+// a ragged batch leaves ~45 % of the time-major rows un-needed, and with one workgroup per 256
+// consecutive rows the launch ran at the speed of its full tiles while the workgroups of late time
+// steps idled (128 us at cfg3 for 54 % of the rows).  Here the units (256-row tile of the list, 64-column
+// tile of Wcat) are ordered tile-major and cut into gridDim.x equal contiguous ranges; a workgroup
+// runs the A-stationary GEMM of k_inproj_fwd_rs2 over each (tile, column range) segment of its range
+// (at most a few tiles: the X fragments are re-loaded per segment).  N is split, not K: no partial sums.
+template <int KS>
+__global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* __restrict__ X,
+                                                       const int* __restrict__ rows, const int* __restrict__ nrows,
+                                                       const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
+                                                       float* __restrict__ G, float* __restrict__ Kk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
+    unsigned char* Bs = ip_lds;                                          // 2 x 64 * KS * 64 bytes (two W tile buffers)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char* scr = ip_lds + 2 * 64 * KS * 64 + wave * 8192;        // [32 rows][64 cols] fp32, 256-byte rows
+    const int M = s.M, G2 = 2 * s.Gp, ntn = s.Ncat / 64;
+    const int n = nrows[0] < M ? nrows[0] : M;                           // list 0: rows with need != 0
+    const long long U = (long long)((n + 255) / 256) * ntn;
+    long long u = U * blockIdx.x / gridDim.x;
+    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    const int sc = lane & 15;
+    while (u < u1) {
+        const int tile = (int)(u / ntn), nt0 = (int)(u - (long long)tile * ntn);
+        const int nt1 = (long long)(ntn - nt0) < u1 - u ? ntn : nt0 + (int)(u1 - u);
+        u += nt1 - nt0;
+        const int j0 = tile * 256 + wave * 32;
+        int mrow[2];
+        int any = 0;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int j = j0 + tm * 16 + (lane & 15);
+            mrow[tm] = j < n ? rows[j] : M;
+            any |= j < n;
+        }
+        const bool wave_any = __any(any);
+        // store side: lane -> list rows (lane >> 4) + 4 i of the wave's 32, 16-byte chunk lane & 15 of the 256-byte row
+        int srow[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = j0 + (lane >> 4) + 4 * i;
+            srow[i] = j < n ? rows[j] : -1;
+        }
+        rs_gemm<KS, 2, true>(X, M, mrow, wave_any, 1, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
+            if (!wave_any) return;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int r = tm * 16 + (lane & 15);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int c = tn * 4 + (lane >> 4);
+                    *(f32x4*)&scr[r * 256 + ((c ^ (r & 15)) << 4)] = acc[tm][tn];
+                }
+            }
+            const int nn = nt * 64 + sc * 4;
+            const f32x4 bias = *(const f32x4*)&bcat[nn];
+            float* base = nn < G2 ? G + nn : Kk + (nn - G2);
+            const long long ld = nn < G2 ? s.Gld : s.Hp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (lane >> 4) + 4 * i;
+                const f32x4 v = *(const f32x4*)&scr[r * 256 + ((sc ^ (r & 15)) << 4)];
+                // written once, read once by the recurrence much later: keep it out of the L2's way
+                if (srow[i] >= 0) __builtin_nontemporal_store(v + bias, (f32x4*)(base + (long long)srow[i] * ld));
+            }
+        });
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight packing: fp32 state_dict tensors -> padded / permuted / transposed bf16 (or fp32) images.
 // dst[r][c] = src[sr][sc] with (sr, sc) = TR ? (cmap(c), rmap(r)) : (rmap(r), cmap(c)); -1 -> 0.

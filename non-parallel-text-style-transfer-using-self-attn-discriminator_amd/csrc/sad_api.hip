@@ -560,15 +560,17 @@ int run_inproj_fwd(const Ctx& c) {
     const bf16raw* X = at<bf16raw>(c.ws, c.wl.off[SAD_WS_X]);
     float* G = at<float>(c.ws, c.wl.off[SAD_WS_G]);
     float* Kk = at<float>(c.ws, c.wl.off[SAD_WS_KK]);
-    if (s.Ep == 320 && s.Ncat % 64 == 0) {   // A-stationary + wave-private output turn (E = 289..320)
+    if (s.Ep == 320 && s.Ncat % 64 == 0) {
+        // A-stationary + wave-private output turn (E = 289..320), over the compacted list of needed rows
+        // (k_row_lists of this call), one workgroup per CU with an equal share of the (row tile, column tile) units
         constexpr size_t lds = 2 * 64 * 10 * 64 + 8 * 8192;
-        allow_lds((const void*)k_inproj_fwd_rs2<10>, lds, 512);
-        const int mtiles = ceil_div(s.M, 256), ntiles = s.Ncat / 64;
-        int nsplit = device_cus() / mtiles;      // one round of workgroups (measured: 8 -> 142 us, 2 -> 130 us)
-        nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
-        const int nt_per = ceil_div(ntiles, nsplit);
-        hipLaunchKernelGGL((k_inproj_fwd_rs2<10>), dim3(mtiles, ceil_div(ntiles, nt_per)), dim3(512), lds, c.st, s, X, need,
-                           at<bf16raw>(c.packed, c.pl.wcat), at<float>(c.packed, c.pl.bcat), G, Kk, nt_per);
+        allow_lds((const void*)k_inproj_fwd_rs3<10>, lds, 512);
+        const long long units = (long long)ceil_div(s.M, 256) * (s.Ncat / 64);
+        const int cus = device_cus();
+        const int grid = units < cus ? (int)units : cus;
+        hipLaunchKernelGGL((k_inproj_fwd_rs3<10>), dim3(grid), dim3(512), lds, c.st, s, X,
+                           at<int>(c.ws, c.wl.off[SAD_WS_ROWS]), at<int>(c.ws, c.wl.off[SAD_WS_NROWS]),
+                           at<bf16raw>(c.packed, c.pl.wcat), at<float>(c.packed, c.pl.bcat), G, Kk);
     } else {
         typedef CfgSquare C;
         dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
@@ -835,6 +837,10 @@ int forward_impl(const Ctx& c, const sad_fwd_args* a) {
     // (k_prep also zeroes the hand-off counters and timeout words of the recurrence)
     int rc = run_prep(s, c.wl, c.ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, c.st);
     if (rc) return rc;
+    // compacted lists of the needed token rows (in-projection here, weight gradients later)
+    hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(s.M, 1024)), dim3(256), 0, c.st, s, at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]),
+                       at<int>(c.ws, c.wl.off[SAD_WS_ROWS]), at<int>(c.ws, c.wl.off[SAD_WS_NROWS]));
+    SAD_CHECK_LAUNCH("k_row_lists");
     // K1 / gather
     if (a->src_kind == SAD_SRC_IDS) {
         if (check_aligned(a->src, 8, "src")) return -1;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 200 /* 0.2.0 */
+#define SAD_VERSION 210 /* 0.2.1 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -41,7 +41,17 @@ typedef struct sad_dims {
     int32_t E; /* embedding size */
     int32_t H; /* LSTM hidden size per direction */
     int32_t L; /* labels (<= 64) */
+    int32_t cell; /* SAD_CELL_LSTM / SAD_CELL_GRU (reference classifier/models.py:102-110: getattr(nn, cell)) */
 } sad_dims;
+
+/* Recurrent cell.  The GRU runs in the LSTM's four-slot gate layout: the caller hands in
+ *   weight_ih = [W_ir; W_iz; W_in; 0]   bias_ih = [b_ir; b_iz; b_in; 0]
+ *   weight_hh = [W_hr; W_hz; 0; W_hn]   bias_hh = [b_hr; b_hz; 0; b_hn]        (each [4H, .])
+ * so that slot 2 is the input half and slot 3 the hidden half of the candidate gate
+ *   n = tanh(slot2 + r * slot3),  h' = (1 - z) * n + z * h      (torch.nn.GRU);
+ * gradients come back in the same four-slot layout (the zero blocks receive values to be dropped). */
+#define SAD_CELL_LSTM 0
+#define SAD_CELL_GRU 1
 
 /* The reference module's fp32 parameters (state_dict layout, reference transfer/models.py:757-829;
  * output_bridge.* and hidden_bridges.1.* never reach the logits and are not needed). Index 0 =
@@ -63,6 +73,21 @@ typedef struct sad_weights {
     const float* output_layer_weight;    /* [L,H]  */
     const float* output_layer_bias;      /* [L]    */
 } sad_weights;
+
+/* One RNN layer ABOVE the first (enc_num_layers > 1; reference classifier/models.py:104-110 -> nn.LSTM / nn.GRU
+ * with num_layers: layer l consumes the per-step outputs [h_fwd | h_rev] of layer l-1).  Each such layer runs
+ * with its own weight image and workspace, both built by the caller with the dims
+ *     {B, T, V = 1, E = 2H, H, L, cell}
+ * where only the rnn_* tensors of sad_weights are this layer's (`weight_ih_l<l>` [4H, 2H], ...) and every other
+ * tensor is zero.  Calls with upper layers run the per-step recurrence kernels in every layer. */
+#define SAD_MAX_UPPER_LAYERS 7
+typedef struct sad_rnn_layer {
+    const void* packed;       /* sad_pack_weights image of this layer */
+    void* workspace;          /* sad_workspace_bytes of this layer's dims; 256-byte aligned */
+    const uint8_t* drop_keep; /* [T,B,2H] bytes, 1 = keep, or NULL: inverted dropout on this layer's INPUT (nn.LSTM's
+                                 inter-layer dropout in training mode, classifier/models.py:108) */
+    float drop_scale;
+} sad_rnn_layer;
 
 typedef struct sad_fwd_args {
     const void* src;          /* ids / soft tokens, see src_kind */
@@ -93,6 +118,8 @@ typedef struct sad_fwd_args {
     const float* onehot_val;    /* [B,T] */
     int64_t onehot_stride_b;
     int64_t onehot_stride_t;
+    const sad_rnn_layer* upper; /* layers above the first, bottom-up, or NULL */
+    int32_t n_upper;            /* 0 .. SAD_MAX_UPPER_LAYERS */
 } sad_fwd_args;
 
 typedef struct sad_bwd_args {
@@ -111,6 +138,8 @@ typedef struct sad_bwd_args {
     int64_t dsrc_stride_t;
     const uint8_t* drop_keep; /* the forward's dropout mask (or NULL) and scale: applied to d(embedded tokens) */
     float drop_scale;
+    const sad_rnn_layer* upper; /* exactly what the matching sad_forward got */
+    int32_t n_upper;
 } sad_bwd_args;
 
 /* Gradient tensors of the live parameters, fp32, state_dict layout (same shapes as sad_weights).
@@ -132,6 +161,8 @@ typedef struct sad_param_grads {
     float* linear_attn_bias;
     float* output_layer_weight;
     float* output_layer_bias;
+    const void* final_hidden_workspace; /* multi-layer only: workspace of the LAST layer (its final hidden states are
+                                           the input of hidden_bridges[0]); NULL = the workspace of the call */
 } sad_param_grads;
 
 /* Named regions of the workspace, for tests / profiling (sad_workspace_field). */

@@ -28,11 +28,14 @@ struct Shape {
     int Vp;    // V rounded up to 64   (K of the soft-embedding GEMM, rows of the packed embedding)
     int Ncat;  // 2*Gp + Hp            (fused in-projection columns: fwd gates | rev gates | attention keys)
     int M;     // T*B token rows
+    int cell;  // 0 = LSTM, 1 = GRU (four-slot layout [r, z, n_input, n_hidden], include/sad.h)
     int Gld;   // row pitch of G in floats: 2*Gp + 64 (breaks the power-of-two 16 KB pitch: 16-row store
                // instructions at a 2^k pitch camp on one HBM channel)
 };
 
-__host__ __device__ inline Shape make_shape(int B, int T, int V, int E, int H, int L) {
+constexpr int CELL_LSTM = 0, CELL_GRU = 1;   // == SAD_CELL_* of include/sad.h
+
+__host__ __device__ inline Shape make_shape(int B, int T, int V, int E, int H, int L, int cell = 0) {
     Shape s;
     s.B = B; s.T = T; s.V = V; s.E = E; s.H = H; s.L = L;
     s.Ep = ceil_to(E, 32);
@@ -42,6 +45,7 @@ __host__ __device__ inline Shape make_shape(int B, int T, int V, int E, int H, i
     s.Ncat = 2 * s.Gp + s.Hp;
     s.M = T * B;
     s.Gld = 2 * s.Gp + 64;
+    s.cell = cell;
     return s;
 }
 

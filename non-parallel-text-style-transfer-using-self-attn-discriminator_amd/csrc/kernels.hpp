@@ -782,6 +782,25 @@ __global__ void k_embed_gather(Shape s, const long long* __restrict__ ids, long 
 // Inverted dropout on the embedded tokens (classifier copy in training mode, classifier/models.py:217),
 // with the caller's keep mask [M][E]:  X[m][e] = keep ? X[m][e] * scale : 0.  The same kernel masks
 // d(embedded tokens) in the backward.  One 16-byte chunk per thread.
+// Input of RNN layer l+1 = per-step outputs of layer l (nn.LSTM with num_layers > 1, reference
+// classifier/models.py:104-110):  X[m][dir*H + j] = Hs[m][dir][j], zeros for padded steps and padded columns,
+// times the inter-layer dropout mask when given.  sl = lower layer's shape, su = upper layer's (su.E == 2*sl.H).
+__global__ void k_hs_to_x(Shape sl, Shape su, const int* __restrict__ lens, const bf16raw* __restrict__ Hs,
+                          const unsigned char* __restrict__ keep, float scale, bf16raw* __restrict__ X) {
+    const long long total = (long long)su.M * su.Ep;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / su.Ep), c = (int)(i - (long long)m * su.Ep);
+        const int t = m / sl.B, b = m - t * sl.B;
+        float v = 0.f;
+        if (c < 2 * sl.H && t < lens[b]) {
+            const int dir = c / sl.H, j = c - dir * sl.H;
+            v = bf16_to_f32(Hs[((long long)m * 2 + dir) * sl.Hp + j]);
+            if (keep != nullptr) v = keep[(long long)m * su.E + c] ? v * scale : 0.f;
+        }
+        X[i] = f32_to_bf16(v);
+    }
+}
+
 __global__ void k_apply_keep(Shape s, bf16raw* __restrict__ X, const unsigned char* __restrict__ keep, float scale) {
     const int cpr = s.Ep / 8;
     const long long total = (long long)s.M * cpr;
@@ -915,14 +934,28 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
         const f32x4 pg = acc[tm][2] + pre[tm][2];
         const f32x4 po = acc[tm][3] + pre[tm][3];
         f32x4 gi, gf, gg, go, c, h;
+        if (s.cell == CELL_GRU) {
+            // slots [r, z, n_input, n_hidden]; Cs carries the fp32 hidden state (cp = h_prev); G keeps
+            // [r, z, n, W_hn h + b_hn] for the BPTT (torch.nn.GRU; reference classifier/models.py:102-110)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            gi[e] = sigmoidf_(pi[e]);
-            gf[e] = sigmoidf_(pf[e]);
-            gg[e] = tanhf_(pg[e]);
-            go[e] = sigmoidf_(po[e]);
-            c[e] = gf[e] * cp[tm][e] + gi[e] * gg[e];
-            h[e] = go[e] * tanhf_(c[e]);
+            for (int e = 0; e < 4; ++e) {
+                gi[e] = sigmoidf_(pi[e]);
+                gf[e] = sigmoidf_(pf[e]);
+                go[e] = po[e];
+                gg[e] = tanhf_(pg[e] + gi[e] * po[e]);
+                c[e] = (1.f - gf[e]) * gg[e] + gf[e] * cp[tm][e];
+                h[e] = c[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gi[e] = sigmoidf_(pi[e]);
+                gf[e] = sigmoidf_(pf[e]);
+                gg[e] = tanhf_(pg[e]);
+                go[e] = sigmoidf_(po[e]);
+                c[e] = gf[e] * cp[tm][e] + gi[e] * gg[e];
+                h[e] = go[e] * tanhf_(c[e]);
+            }
         }
         if (!(dbg & 2)) {
             *(f32x4*)(g + 0) = gi;
@@ -1238,15 +1271,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2'  one BPTT step of the LSTM (both directions), frozen weights:
-//   dh_t = dZ_{next} . W_hh  (+ d h_final at the row's last forward step), gate derivatives,
+// K2'  one BPTT step of the LSTM / GRU (both directions), frozen weights:
+//   dh_t = dZ_{next} . W_hh  (+ d h_final at the row's last forward step) (+ DHS[t]: the gradient of the step's
+//   output when another RNN layer consumes it), gate derivatives,
 //   dZ_t -> DZ (bf16, zeros for t >= len[b]); dc carried in DC.
 // ------------------------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int* __restrict__ lens,
                                                    const bf16raw* __restrict__ whhT, const float* __restrict__ G,
                                                    const float* __restrict__ Cs, const float* __restrict__ DHFIN,
-                                                   float* __restrict__ DC, bf16raw* __restrict__ DZ) {
+                                                   float* __restrict__ DC, bf16raw* __restrict__ DZ,
+                                                   const bf16raw* __restrict__ DHS, int ldh) {
     __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
     __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
     const int dir = blockIdx.z;
@@ -1295,6 +1330,13 @@ __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int
             if (tpf_ok && len > tpf) p.cp = *(const f32x4*)&Cs[(((long long)tpf * B + b) * 2 + dir) * Hp + j];
             if (tn_ok && len > tn) p.dc = *(const f32x4*)&DC[(long long)b * 2 * Hp + dir * Hp + j];
             if (last) p.dhf = *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + j];
+            if (DHS != nullptr) {
+                // gradient of this step's output from the layer above: d(input of layer l+1)[t][b][dir*H + unit]
+                const bf16raw* q = DHS + ((long long)t * B + b) * ldh + dir * s.H + j;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < s.H) p.dhf[e] += bf16_to_f32(q[e]);
+            }
         }
     }
     if (any && tn_ok) {
@@ -1327,16 +1369,31 @@ __global__ __launch_bounds__(C::NT) void k_lstm_bwd(Shape s, int step, const int
             const Pre& p = pre[tm][tnn];
             const f32x4 dh = acc[tm][tnn] + p.dhf;
             f32x4 zi, zf, zg, zo, dcn;
+            if (s.cell == CELL_GRU) {
+                // G = [r, z, n, q = W_hn h + b_hn], cp = h_prev, DC carries dh * z to the previous step
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float tc = tanhf_(p.c[e]);
-                const float d_o = dh[e] * tc;
-                const float dct = p.dc[e] + dh[e] * p.go[e] * (1.f - tc * tc);
-                zi[e] = dct * p.gg[e] * p.gi[e] * (1.f - p.gi[e]);
-                zf[e] = dct * p.cp[e] * p.gf[e] * (1.f - p.gf[e]);
-                zg[e] = dct * p.gi[e] * (1.f - p.gg[e] * p.gg[e]);
-                zo[e] = d_o * p.go[e] * (1.f - p.go[e]);
-                dcn[e] = dct * p.gf[e];
+                for (int e = 0; e < 4; ++e) {
+                    const float dht = dh[e] + p.dc[e];
+                    const float r = p.gi[e], z = p.gf[e], n = p.gg[e], q = p.go[e];
+                    const float da = dht * (1.f - z) * (1.f - n * n);
+                    zi[e] = da * q * r * (1.f - r);
+                    zf[e] = dht * (p.cp[e] - n) * z * (1.f - z);
+                    zg[e] = da;
+                    zo[e] = da * r;
+                    dcn[e] = dht * z;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tc = tanhf_(p.c[e]);
+                    const float d_o = dh[e] * tc;
+                    const float dct = p.dc[e] + dh[e] * p.go[e] * (1.f - tc * tc);
+                    zi[e] = dct * p.gg[e] * p.gi[e] * (1.f - p.gi[e]);
+                    zf[e] = dct * p.cp[e] * p.gf[e] * (1.f - p.gf[e]);
+                    zg[e] = dct * p.gi[e] * (1.f - p.gg[e] * p.gg[e]);
+                    zo[e] = d_o * p.go[e] * (1.f - p.go[e]);
+                    dcn[e] = dct * p.gf[e];
+                }
             }
             *(u32x2*)&zrow[pc + 0] = pack_bf16x4(zi);
             *(u32x2*)&zrow[pc + 16] = pack_bf16x4(zf);

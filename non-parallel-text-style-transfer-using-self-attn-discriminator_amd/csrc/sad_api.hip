@@ -191,7 +191,8 @@ int check_dims(const sad_dims* d, Shape* s) {
     if (d->H > 2048) return fail(-1, "H=%d exceeds the supported maximum 2048", d->H);
     if ((long long)d->B * d->T > (1ll << 30)) return fail(-1, "B*T too large");
     if (d->B > 65535 * 64) return fail(-1, "B too large");
-    *s = make_shape(d->B, d->T, d->V, d->E, d->H, d->L);
+    if (d->cell != SAD_CELL_LSTM && d->cell != SAD_CELL_GRU) return fail(-1, "cell=%d is neither SAD_CELL_LSTM nor SAD_CELL_GRU", d->cell);
+    *s = make_shape(d->B, d->T, d->V, d->E, d->H, d->L, d->cell);
     return 0;
 }
 
@@ -360,12 +361,14 @@ bool persist_fits(const void* kernel, size_t lds, int grid, int threads) {
 }
 // forward recurrence: half-width workgroups, two per CU
 bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
+    if (s.cell != SAD_CELL_LSTM) return false;   // the GRU runs the per-step kernels
     if (s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
     if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
     *grid = 2 * ceil_div(s.B, LF_BM) * (s.Gp / LF_BN);
     return persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256);
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
+    if (s.cell != SAD_CELL_LSTM) return false;
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
     *grid = 2 * ceil_div(s.B, LB_BM) * (s.Hp / LB_BN);
     return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512);
@@ -551,6 +554,7 @@ struct Ctx {
     const void* packed;
     void* ws;
     hipStream_t st;
+    bool per_step = false;   // multi-layer calls: every layer runs the per-step recurrence kernels (fp32 gates in G)
 };
 
 // K2a + K3: [G | Kk] = X . Wcat^T + bcat
@@ -592,7 +596,7 @@ int run_lstm_fwd(const Ctx& c) {
     bf16raw* Hs = at<bf16raw>(c.ws, c.wl.off[SAD_WS_HS]);
     const bf16raw* whh = at<bf16raw>(c.packed, c.pl.whh);
     int pgrid = 0;
-    if (lstm_fwd_persist_fits(s, &pgrid)) {
+    if (!c.per_step && lstm_fwd_persist_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), c.st, s, lens, whh, G, Cs,
                            Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
@@ -616,10 +620,11 @@ int run_lstm_fwd(const Ctx& c) {
 }
 
 // K4: q = hidden_bridges[0]([h_fwd | h_rev]), u = linear_q(q)
-int run_bridge_fwd(const Ctx& c) {
+// (`top`: context whose HS holds the final hidden states — the last layer's for a multi-layer RNN)
+int run_bridge_fwd(const Ctx& c, const Ctx& top) {
     const Shape& s = c.s;
     const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
-    const bf16raw* Hs = at<bf16raw>(c.ws, c.wl.off[SAD_WS_HS]);
+    const bf16raw* Hs = at<bf16raw>(top.ws, top.wl.off[SAD_WS_HS]);
     float* Q = at<float>(c.ws, c.wl.off[SAD_WS_Q]);
     float* U = at<float>(c.ws, c.wl.off[SAD_WS_U]);
     typedef CfgSmall C;
@@ -685,12 +690,13 @@ int run_attn_bwd(const Ctx& c, const sad_bwd_args* a) {
 }
 
 // K4': dq = du . W_q ; d[h_fwd | h_rev] = dq . W_hb0
-int run_bridge_bwd(const Ctx& c) {
+// (`top`: context that receives d(final hidden) — the last layer's for a multi-layer RNN)
+int run_bridge_bwd(const Ctx& c, const Ctx& top) {
     const Shape& s = c.s;
     const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
     float* DU = at<float>(c.ws, c.wl.off[SAD_WS_DU]);
     float* DQ = at<float>(c.ws, c.wl.off[SAD_WS_DQ]);
-    float* DHFIN = at<float>(c.ws, c.wl.off[SAD_WS_DHFIN]);
+    float* DHFIN = at<float>(top.ws, top.wl.off[SAD_WS_DHFIN]);
     typedef CfgSmall C;
     dim3 g1(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
     hipLaunchKernelGGL((k_linear<C, 0>), g1, dim3(C::NT), 0, c.st, s, s.B, s.Hp, s.Hp, (const void*)DU, s.Hp, lens,
@@ -705,7 +711,9 @@ int run_bridge_bwd(const Ctx& c) {
 // K2': BPTT.  Persistent kernel (one launch) when its grid is co-resident, else T launches.  The
 // hand-off counters must be zero (k_attn_bwd of the same call, or run_zero_sync); the timeout words
 // behind them keep what the forward left.
-int run_lstm_bwd(const Ctx& c) {
+// `dhs` (bf16 [T*B][ldh], column dir*H + unit, or NULL): gradient of every step's output when a layer above
+// consumed it; only the per-step kernel takes it.
+int run_lstm_bwd(const Ctx& c, const bf16raw* dhs = nullptr, int ldh = 0) {
     const Shape& s = c.s;
     const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
     const float* G = at<float>(c.ws, c.wl.off[SAD_WS_G]);
@@ -715,7 +723,7 @@ int run_lstm_bwd(const Ctx& c) {
     bf16raw* DZ = at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZ]);
     const bf16raw* whhT = at<bf16raw>(c.packed, c.pl.whhT);
     int pgrid = 0;
-    if (lstm_bwd_persist_fits(s, &pgrid)) {
+    if (!c.per_step && dhs == nullptr && lstm_bwd_persist_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), c.st, s, lens, whhT, G,
                            Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr,
@@ -725,7 +733,7 @@ int run_lstm_bwd(const Ctx& c) {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;
             dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM), 2);
-            hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, c.st, s, step, lens, whhT, G, Cs, DHFIN, DC, DZ);
+            hipLaunchKernelGGL((k_lstm_bwd<C>), grid, dim3(C::NT), 0, c.st, s, step, lens, whhT, G, Cs, DHFIN, DC, DZ, dhs, ldh);
         }
     }
     SAD_CHECK_LAUNCH("k_lstm_bwd");
@@ -826,9 +834,49 @@ int noalloc_scratch(unsigned char** out) {
     return 0;
 }
 
-int forward_impl(const Ctx& c, const sad_fwd_args* a) {
-    const Shape& s = c.s;
+// Context of RNN layer i above the first: dims {B, T, 1, 2H, H, L, cell}, the caller's image and workspace.
+int make_upper_ctx(const Ctx& c0, const sad_rnn_layer* upper, int n_upper, int i, Ctx* cu) {
+    if (n_upper < 0 || n_upper > SAD_MAX_UPPER_LAYERS) return fail(-1, "n_upper=%d outside 0..%d", n_upper, SAD_MAX_UPPER_LAYERS);
+    if (upper == nullptr) return fail(-1, "n_upper=%d but upper is NULL", n_upper);
+    sad_dims du = {c0.s.B, c0.s.T, 1, 2 * c0.s.H, c0.s.H, c0.s.L, c0.s.cell};
+    if (make_ctx(&du, upper[i].packed, upper[i].workspace, (void*)c0.st, cu)) return -1;
+    cu->per_step = true;
+    return 0;
+}
+
+// Layers above the first: input = per-step outputs of the layer below, in-projection, recurrence.
+int run_upper_fwd(const Ctx& c0, const sad_fwd_args* a) {
+    const Ctx* below = &c0;
+    Ctx cu[SAD_MAX_UPPER_LAYERS];
+    for (int i = 0; i < a->n_upper; ++i) {
+        int rc = make_upper_ctx(c0, a->upper, a->n_upper, i, &cu[i]);
+        if (rc) return rc;
+        const Ctx& c = cu[i];
+        // lengths / need bits / row lists / zeroed counters of this layer's workspace (the mask was already
+        // mutated by layer 0's k_prep; the guard is idempotent)
+        if ((rc = run_prep(c.s, c.wl, c.ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, c.st)) != 0) return rc;
+        hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(c.s.M, 1024)), dim3(256), 0, c.st, c.s,
+                           at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]), at<int>(c.ws, c.wl.off[SAD_WS_ROWS]),
+                           at<int>(c.ws, c.wl.off[SAD_WS_NROWS]));
+        const long long total = (long long)c.s.M * c.s.Ep;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_hs_to_x, dim3(blocks), dim3(256), 0, c.st, below->s, c.s, at<int>(c.ws, c.wl.off[SAD_WS_LENS]),
+                           at<bf16raw>(below->ws, below->wl.off[SAD_WS_HS]), a->upper[i].drop_keep, a->upper[i].drop_scale,
+                           at<bf16raw>(c.ws, c.wl.off[SAD_WS_X]));
+        SAD_CHECK_LAUNCH("k_hs_to_x");
+        if ((rc = run_inproj_fwd(c)) != 0) return rc;
+        if ((rc = run_lstm_fwd(c)) != 0) return rc;
+        below = &cu[i];
+    }
+    return run_bridge_fwd(c0, *below);
+}
+
+int forward_impl(const Ctx& c_in, const sad_fwd_args* a) {
     if (check_ptr(a, "args")) return -1;
+    Ctx c = c_in;
+    c.per_step = a->n_upper != 0;
+    const Shape& s = c.s;
     if (check_ptr(a->src, "src") || check_ptr(a->lengths, "lengths") || check_ptr(a->mask, "mask") ||
         check_ptr(a->logits, "logits") || check_ptr(a->weights, "weights"))
         return -1;
@@ -870,7 +918,7 @@ int forward_impl(const Ctx& c, const sad_fwd_args* a) {
     if (a->drop_keep != nullptr && (rc = run_apply_keep(c, X, a->drop_keep, a->drop_scale)) != 0) return rc;
     if ((rc = run_inproj_fwd(c)) != 0) return rc;
     if ((rc = run_lstm_fwd(c)) != 0) return rc;
-    if ((rc = run_bridge_fwd(c)) != 0) return rc;
+    if ((rc = a->n_upper ? run_upper_fwd(c, a) : run_bridge_fwd(c, c)) != 0) return rc;
     return run_attn_fwd(c, a->labels, a->logits, a->weights, a->loss);
 }
 
@@ -897,8 +945,37 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     if (check_bwd_args(a)) return -1;
     int rc;
     if ((rc = run_attn_bwd(c, a)) != 0) return rc;
-    if ((rc = run_bridge_bwd(c)) != 0) return rc;
-    if ((rc = run_lstm_bwd(c)) != 0) return rc;
+    if (a->n_upper == 0) {
+        if ((rc = run_bridge_bwd(c, c)) != 0) return rc;
+        if ((rc = run_lstm_bwd(c)) != 0) return rc;
+    } else {
+        // top-down through the layers above the first: d(final hidden) enters the last layer only; every
+        // layer's d(input) is the per-step output gradient of the layer below it
+        c.per_step = true;
+        Ctx cu[SAD_MAX_UPPER_LAYERS];
+        for (int i = 0; i < a->n_upper; ++i)
+            if ((rc = make_upper_ctx(c, a->upper, a->n_upper, i, &cu[i])) != 0) return rc;
+        const int top = a->n_upper - 1;
+        if ((rc = run_bridge_bwd(c, cu[top])) != 0) return rc;
+        const bf16raw* dhs = nullptr;
+        for (int i = top; i >= 0; --i) {
+            const Ctx& u = cu[i];
+            // the key columns of this layer's dZ have no producer (no attention on upper layers): all zero
+            if (hipMemsetAsync(at<unsigned char>(u.ws, u.wl.off[SAD_WS_DZ]), 0, u.wl.bytes[SAD_WS_DZ], u.st) != hipSuccess)
+                return fail(-2, "hipMemsetAsync(DZ) failed");
+            if (i != top && hipMemsetAsync(at<unsigned char>(u.ws, u.wl.off[SAD_WS_DHFIN]), 0, u.wl.bytes[SAD_WS_DHFIN], u.st) != hipSuccess)
+                return fail(-2, "hipMemsetAsync(DHFIN) failed");
+            if ((rc = run_lstm_bwd(u, dhs, u.s.Ep)) != 0) return rc;
+            if ((rc = run_inproj_bwd(u)) != 0) return rc;
+            if (a->upper[i].drop_keep != nullptr &&
+                (rc = run_apply_keep(u, at<bf16raw>(u.ws, u.wl.off[SAD_WS_DX]), a->upper[i].drop_keep, a->upper[i].drop_scale)) != 0)
+                return rc;
+            dhs = at<bf16raw>(u.ws, u.wl.off[SAD_WS_DX]);
+        }
+        if (hipMemsetAsync(at<unsigned char>(c.ws, c.wl.off[SAD_WS_DHFIN]), 0, c.wl.bytes[SAD_WS_DHFIN], c.st) != hipSuccess)
+            return fail(-2, "hipMemsetAsync(DHFIN) failed");
+        if ((rc = run_lstm_bwd(c, dhs, cu[0].s.Ep)) != 0) return rc;
+    }
     if ((rc = run_inproj_bwd(c)) != 0) return rc;
     // d(embedded tokens) in front of the dropout
     if (a->drop_keep != nullptr &&
@@ -1149,7 +1226,11 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         typedef WCfg<64, 64, 2, 2> W;
         if (g->hidden_bridge0_weight != nullptr) {
             const int t1 = ceil_div(s.Hp, W::BN1), t2 = ceil_div(2 * s.Hp, W::BN2);
-            launch_wg<W>(k_wgrad_dense<W, 1>, dim3(t1, t2, row_split(s.B, t1 * t2)), st, s, DQ, (const void*)Hs, 2 * s.Hp,
+            const bf16raw* Hfin = Hs;
+            if (g->final_hidden_workspace != nullptr)       // the last RNN layer's workspace (dims of a sad_rnn_layer)
+                Hfin = at<bf16raw>(g->final_hidden_workspace,
+                                   ws_layout(make_shape(s.B, s.T, 1, 2 * s.H, s.H, s.L, s.cell)).off[SAD_WS_HS]);
+            launch_wg<W>(k_wgrad_dense<W, 1>, dim3(t1, t2, row_split(s.B, t1 * t2)), st, s, DQ, (const void*)Hfin, 2 * s.Hp,
                          lens, g->hidden_bridge0_weight);
         }
         if (g->linear_q_weight != nullptr) {

@@ -28,6 +28,9 @@ _LIVE_PARAMS = (
 )
 
 
+_RNN_PARAMS = _LIVE_PARAMS[1:9]      # the eight rnn.* tensors: all a layer above the first owns
+
+
 def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -40,10 +43,11 @@ class PackedWeights:
     """Device image of the discriminator weights in the kernels' layout (bf16, padded to MFMA tile
     multiples, LSTM gate rows permuted, plus pre-transposed copies for the backward GEMMs)."""
 
-    def __init__(self, V, E, H, L, device):
-        self.V, self.E, self.H, self.L = int(V), int(E), int(H), int(L)
+    def __init__(self, V, E, H, L, device, cell=_lib.CELL_LSTM):
+        self.V, self.E, self.H, self.L, self.cell = int(V), int(E), int(H), int(L), int(cell)
         self.device = torch.device(device)
-        d = _lib.dims(1, 1, V, E, H, L)
+        self.upper = []      # PackedWeights of the RNN layers above the first (dims V=1, E=2H)
+        d = _lib.dims(1, 1, V, E, H, L, cell)
         nbytes = _lib.load().sad_packed_bytes(ctypes.byref(d))
         if nbytes == 0:
             raise RuntimeError("libsad sad_packed_bytes failed: " + _lib.last_error())
@@ -79,22 +83,47 @@ class PackedWeights:
         w.linear_attn_bias = p("linear_attn.bias")
         w.output_layer_weight = p("output_layer.weight")
         w.output_layer_bias = p("output_layer.bias")
-        d = _lib.dims(1, 1, self.V, self.E, self.H, self.L)
+        d = _lib.dims(1, 1, self.V, self.E, self.H, self.L, self.cell)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().sad_pack_weights(ctypes.byref(d), ctypes.byref(w), _ptr(self.buf), _stream_ptr()),
                        "sad_pack_weights")
         return self
 
 
-def pack_weights(params, V=None, E=None, H=None, L=None):
+_zero_cache = {}
+
+
+def _upper_canonical(rnn_params, H, L, dev):
+    """The 19-tensor mapping of an RNN layer above the first: its own rnn.* tensors (input width 2H), zeros
+    for everything else (include/sad.h, sad_rnn_layer)."""
+    key = (H, L, str(dev))
+    z = _zero_cache.get(key)
+    if z is None:
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        z = {"embedding.weight": f(1, 2 * H), "hidden_bridges.0.weight": f(H, 2 * H), "hidden_bridges.0.bias": f(H),
+             "linear_emb.weight": f(H, 2 * H), "linear_emb.bias": f(H), "linear_q.weight": f(H, H),
+             "linear_q.bias": f(H), "linear_attn.weight": f(1, H), "linear_attn.bias": f(1),
+             "output_layer.weight": f(L, H), "output_layer.bias": f(L)}
+        _zero_cache[key] = z
+    out = dict(z)
+    out.update({k: rnn_params[k] for k in _RNN_PARAMS})
+    return out
+
+
+def pack_weights(params, V=None, E=None, H=None, L=None, cell=_lib.CELL_LSTM, upper=()):
     """Build a PackedWeights from a name->tensor mapping (a module's ``state_dict()`` or
-    ``dict(named_parameters())``)."""
+    ``dict(named_parameters())``) in the kernels' canonical layout: bidirectional, four gate slots
+    (``cell=CELL_GRU``: include/sad.h).  ``upper``: one mapping of the eight ``rnn.*_l0*`` names per RNN layer
+    above the first (input width 2H)."""
     emb = params["embedding.weight"]
     V = emb.shape[0] if V is None else V
     E = emb.shape[1] if E is None else E
     H = params["rnn.weight_hh_l0"].shape[1] if H is None else H
     L = params["output_layer.weight"].shape[0] if L is None else L
-    return PackedWeights(V, E, H, L, emb.device).pack(params)
+    pw = PackedWeights(V, E, H, L, emb.device, cell).pack(params)
+    for up in upper:
+        pw.upper.append(PackedWeights(1, 2 * H, H, L, emb.device, cell).pack(_upper_canonical(up, H, L, emb.device)))
+    return pw
 
 
 def _lengths_to_device(src_len, B, device):
@@ -202,7 +231,7 @@ def _grad_struct(views):
     return g
 
 
-_N_FIXED = 9   # forward() arguments in front of *params
+_N_FIXED = 10   # forward() arguments in front of *params
 
 # Debug / profiling hook (tests, bench.py, tools): when True the last call's Workspace and flat
 # gradient bucket stay reachable as _Discriminator.last_workspace / .last_grad_bucket.  Off by
@@ -211,7 +240,10 @@ KEEP_LAST = False
 
 
 class _Discriminator(torch.autograd.Function):
-    """forward(src, lengths, mask, labels, pw, guard, pad_id, drop, onehot, *params).
+    """forward(src, lengths, mask, labels, pw, guard, pad_id, drop, onehot, layer_drop, *params).
+
+    ``layer_drop`` is None or one (keep [T,B,2H] bool/uint8, scale) per RNN layer above the first: nn.LSTM's
+    inter-layer dropout in training mode (reference classifier/models.py:108).
 
     ``onehot`` is None or (ids int64 [B,T], val float32 [B,T]) — the side channel of straight-through
     one-hot soft tokens (producer.SoftTokenAssembler): K1 forward gathers instead of contracting.
@@ -220,16 +252,19 @@ class _Discriminator(torch.autograd.Function):
     tokens with the caller's mask (classifier copy in training mode, reference classifier/models.py:217).
 
     ``params`` is either empty (frozen discriminator: the transfer loop, reference
-    transfer/trainers.py:216-223) or the 19 live parameters in ``_LIVE_PARAMS`` order; those that
+    transfer/trainers.py:216-223) or the 19 live parameters in ``_LIVE_PARAMS`` order followed by the eight
+    ``_RNN_PARAMS`` of every RNN layer above the first; those that
     require grad receive gradients from sad_param_grads_accumulate (classifier training, reference
     classifier/trainers.py:367-373)."""
 
     @staticmethod
-    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, drop, onehot, *params):
+    def forward(ctx, src, lengths_dev, mask, labels, pw, guard, pad_id, drop, onehot, layer_drop, *params):
         if not src.is_cuda:
             raise RuntimeError("sad_amd runs on the HIP device only (got a CPU tensor); there is no CPU fallback")
-        if params and len(params) != len(_LIVE_PARAMS):
-            raise RuntimeError("expected %d live parameters, got %d" % (len(_LIVE_PARAMS), len(params)))
+        n_up = len(pw.upper)
+        if params and len(params) != len(_LIVE_PARAMS) + n_up * len(_RNN_PARAMS):
+            raise RuntimeError("expected %d live parameters, got %d" % (len(_LIVE_PARAMS) + n_up * len(_RNN_PARAMS),
+                                                                        len(params)))
         kind = _src_kind(src)
         B, T = src.shape[0], src.shape[1]
         if kind != _lib.SRC_IDS:
@@ -240,8 +275,23 @@ class _Discriminator(torch.autograd.Function):
         if mask.dtype != torch.bool or mask.shape != (B, T) or mask.device != src.device:
             raise RuntimeError("mask must be a bool [B,T] tensor on the same device as src")
         dev = src.device
-        d = _lib.dims(B, T, pw.V, pw.E, pw.H, pw.L)
+        d = _lib.dims(B, T, pw.V, pw.E, pw.H, pw.L, pw.cell)
         ws = Workspace(d, dev)
+        # RNN layers above the first: own dims / image / workspace each (include/sad.h, sad_rnn_layer)
+        d_up = _lib.dims(B, T, 1, 2 * pw.H, pw.H, pw.L, pw.cell)
+        ws_up = [Workspace(d_up, dev) for _ in range(n_up)]
+        upper = (_lib.SadRnnLayer * max(n_up, 1))()
+        keeps_up = []
+        for i in range(n_up):
+            upper[i].packed, upper[i].workspace = pw.upper[i].buf.data_ptr(), ws_up[i].buf.data_ptr()
+            if layer_drop is not None:
+                keep, scale = layer_drop[i]
+                keep = (keep.view(torch.uint8) if keep.dtype == torch.bool else keep.to(torch.uint8)).to(dev).contiguous()
+                if tuple(keep.shape) != (T, B, 2 * pw.H):
+                    raise RuntimeError("inter-layer dropout keep mask must be [T,B,2H] = %s, got %s"
+                                       % ((T, B, 2 * pw.H), tuple(keep.shape)))
+                keeps_up.append(keep)
+                upper[i].drop_keep, upper[i].drop_scale = keep.data_ptr(), float(scale)
         logits = torch.empty((B, pw.L), dtype=torch.float32, device=dev)
         weights = torch.empty((B, T), dtype=torch.float32, device=dev)
         loss = torch.empty((B,), dtype=torch.float32, device=dev) if labels is not None else None
@@ -273,6 +323,8 @@ class _Discriminator(torch.autograd.Function):
                 raise RuntimeError("onehot = (ids int64 [B,T], val float32 [B,T]) with equal strides on the device of src")
             a.onehot_ids, a.onehot_val = oh_ids.data_ptr(), oh_val.data_ptr()
             a.onehot_stride_b, a.onehot_stride_t = oh_ids.stride(0), oh_ids.stride(1)
+        if n_up:
+            a.upper, a.n_upper = upper, n_up
         with torch.cuda.device(dev):
             _lib.check(_lib.load().sad_forward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
                                                _stream_ptr()), "sad_forward")
@@ -288,6 +340,7 @@ class _Discriminator(torch.autograd.Function):
         ctx.save_for_backward(logits, weights, labels, keep_src)
         ctx.sad = (d, ws, pw, kind, src.shape, src.stride(), src.dtype,
                    -1 if pad_id is None else int(pad_id), [tuple(p.shape) for p in params], drop)
+        ctx.sad_upper = (d_up, ws_up, upper, keeps_up)
         if KEEP_LAST:
             _Discriminator.last_workspace = ws   # introspection hook for tests / profiling
         if loss is None:
@@ -297,6 +350,8 @@ class _Discriminator(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, dweights, dloss=None):
         d, ws, pw, kind, shape, strides, dtype, pad_id, pshapes, drop = ctx.sad
+        d_up, ws_up, upper, keeps_up = ctx.sad_upper
+        n_up = len(ws_up)
         logits, weights, labels, src = ctx.saved_tensors
         n_out = _N_FIXED + len(pshapes)
         want_src = kind != _lib.SRC_IDS and ctx.needs_input_grad[0]
@@ -335,6 +390,8 @@ class _Discriminator(torch.autograd.Function):
             a.dsrc_stride_b, a.dsrc_stride_t = dsrc.stride(0), dsrc.stride(1)
         if drop is not None:
             a.drop_keep, a.drop_scale = drop[0].data_ptr(), drop[1]
+        if n_up:
+            a.upper, a.n_upper = upper, n_up
         pgrads = [None] * len(pshapes)
         with torch.cuda.device(dev):
             lib = _lib.load()
@@ -345,45 +402,61 @@ class _Discriminator(torch.autograd.Function):
                 # it, and a data-parallel caller can all-reduce the bucket as a single message.
                 sizes = [int(torch.Size(s).numel()) if w else 0 for s, w in zip(pshapes, want_p)]
                 flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+                names = list(_LIVE_PARAMS) + ["upper%d.%s" % (i, n) for i in range(n_up) for n in _RNN_PARAMS]
                 views, off = {}, 0
-                for i, (name, s, w) in enumerate(zip(_LIVE_PARAMS, pshapes, want_p)):
+                for i, (name, s, w) in enumerate(zip(names, pshapes, want_p)):
                     if w:
                         pgrads[i] = flat[off:off + sizes[i]].view(s)
                         views[name] = pgrads[i]
                         off += sizes[i]
                 g = _grad_struct(views)
+                if n_up:
+                    g.final_hidden_workspace = ws_up[-1].buf.data_ptr()
                 sp = src.data_ptr() if src is not None else None
                 sb, st_ = (strides[0], strides[1])
                 _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d), ctypes.byref(g), sp, kind, sb, st_, pad_id,
                                                           _ptr(ws.buf), _stream_ptr()), "sad_param_grads_accumulate")
+                for i in range(n_up):
+                    pre = "upper%d." % i
+                    gu = _grad_struct({n: views[pre + n] for n in _RNN_PARAMS if pre + n in views})
+                    _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d_up), ctypes.byref(gu), None, _lib.SRC_IDS, 0, 0,
+                                                              -1, _ptr(ws_up[i].buf), _stream_ptr()),
+                               "sad_param_grads_accumulate(upper layer)")
                 if KEEP_LAST:
                     _Discriminator.last_grad_bucket = flat
         del keep
         return (dsrc,) + (None,) * (_N_FIXED - 1) + tuple(pgrads)
 
 
-def _live(params):
-    """Mapping / None -> tuple of the 19 live tensors in kernel order (empty = frozen)."""
+def _live(params, upper_params=()):
+    """Mapping / None -> tuple of the 19 live tensors in kernel order, then the eight rnn.* tensors of every
+    layer above the first (empty = frozen)."""
     if not params:
         return ()
-    return tuple(params[n] for n in _LIVE_PARAMS)
+    out = [params[n] for n in _LIVE_PARAMS]
+    for up in upper_params:
+        out += [up[n] for n in _RNN_PARAMS]
+    return tuple(out)
 
 
-def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None, drop=None, onehot=None):
+def discriminator(src, src_len, mask, pw, guard=True, params=None, pad_id=None, drop=None, onehot=None,
+                  layer_drop=None, upper_params=()):
     """(logits [B,L], attention weights [B,T]) — the reference module's return value.
 
     ``params`` (name -> nn.Parameter, optional) makes the call differentiable w.r.t. the parameters
     that require grad; without it the discriminator is frozen (gradient flows to soft tokens only)."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
-    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, drop, onehot, *_live(params))
+    return _Discriminator.apply(src, lengths_dev, mask, None, pw, guard, pad_id, drop, onehot, layer_drop,
+                                *_live(params, upper_params))
 
 
-def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None, drop=None, onehot=None):
+def discriminator_loss(src, src_len, mask, labels, pw, guard=True, params=None, pad_id=None, drop=None, onehot=None,
+                       layer_drop=None, upper_params=()):
     """(per-sentence CE loss [B], logits, weights) with the cross entropy fused into the attention
     kernels — what the transfer step computes at reference transfer/models.py:1185-1212."""
     lengths_dev = _lengths_to_device(src_len, src.shape[0], src.device)
     logits, weights, loss = _Discriminator.apply(src, lengths_dev, mask, labels, pw, guard, pad_id, drop, onehot,
-                                                 *_live(params))
+                                                 layer_drop, *_live(params, upper_params))
     return loss, logits, weights
 
 

@@ -28,7 +28,7 @@ DBG_NO_PERSIST, DBG_SPIN_LIMIT, DBG_WITHHOLD_FWD, DBG_WITHHOLD_BWD = 0, 1, 2, 3
 
 
 class SadDims(ctypes.Structure):
-    _fields_ = [(n, c_int32) for n in ("B", "T", "V", "E", "H", "L")]
+    _fields_ = [(n, c_int32) for n in ("B", "T", "V", "E", "H", "L", "cell")]
 
 
 class SadWeights(ctypes.Structure):
@@ -51,8 +51,14 @@ class SadWeights(ctypes.Structure):
     ]
 
 
-class SadParamGrads(SadWeights):
+class SadParamGrads(ctypes.Structure):
     """sad_param_grads: same tensors as sad_weights, writable; NULL = frozen tensor."""
+    _fields_ = SadWeights._fields_ + [("final_hidden_workspace", c_void_p)]
+
+
+class SadRnnLayer(ctypes.Structure):
+    """sad_rnn_layer: one RNN layer above the first."""
+    _fields_ = [("packed", c_void_p), ("workspace", c_void_p), ("drop_keep", c_void_p), ("drop_scale", c_float)]
 
 
 class SadFwdArgs(ctypes.Structure):
@@ -64,6 +70,7 @@ class SadFwdArgs(ctypes.Structure):
         ("logits", c_void_p), ("weights", c_void_p), ("loss", c_void_p),
         ("drop_keep", c_void_p), ("drop_scale", c_float),
         ("onehot_ids", c_void_p), ("onehot_val", c_void_p), ("onehot_stride_b", c_int64), ("onehot_stride_t", c_int64),
+        ("upper", ctypes.POINTER(SadRnnLayer)), ("n_upper", c_int32),
     ]
 
 
@@ -84,6 +91,7 @@ class SadBwdArgs(ctypes.Structure):
         ("dweights", c_void_p), ("logits", c_void_p), ("weights", c_void_p),
         ("dsrc", c_void_p), ("dsrc_kind", c_int32), ("dsrc_stride_b", c_int64), ("dsrc_stride_t", c_int64),
         ("drop_keep", c_void_p), ("drop_scale", c_float),
+        ("upper", ctypes.POINTER(SadRnnLayer)), ("n_upper", c_int32),
     ]
 
 
@@ -153,8 +161,12 @@ def debug_set(key, value):
     check(load().sad_debug_set(int(key), int(value)), "sad_debug_set")
 
 
-def dims(B, T, V, E, H, L):
-    return SadDims(int(B), int(T), int(V), int(E), int(H), int(L))
+CELL_LSTM, CELL_GRU = 0, 1
+MAX_UPPER_LAYERS = 7       # SAD_MAX_UPPER_LAYERS
+
+
+def dims(B, T, V, E, H, L, cell=CELL_LSTM):
+    return SadDims(int(B), int(T), int(V), int(E), int(H), int(L), int(cell))
 
 
 def padded_dims(d):

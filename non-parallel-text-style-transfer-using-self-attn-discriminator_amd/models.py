@@ -11,7 +11,23 @@ reference's two copies:
   ``forward(src, src_len, pad_mask=None, hidden=None, soft=False)``; derives the pad+sos+eos mask
   from the pad mask (:183-187), no all-masked guard; ``set_mask_id`` / ``get_masked_src``.
 
-The submodules (``nn.Embedding``, ``nn.LSTM``, ``nn.Linear``) exist only as PARAMETER HOLDERS so
+Every configuration the reference constructor accepts is covered (reference
+classifier/models.py:102-124): ``cell`` LSTM / GRU, ``enc_bidirectional`` True / False, ``enc_num_layers`` >= 1.
+The kernels run ONE canonical layout — bidirectional, four gate slots per unit — and the variants are
+embedded into it here, with autograd carrying the gradients back to the real parameters:
+
+* GRU: ``weight_ih -> [W_ir; W_iz; W_in; 0]``, ``weight_hh -> [W_hr; W_hz; 0; W_hn]`` (biases alike), cell
+  code ``CELL_GRU`` (include/sad.h);
+* uni-directional: the reverse direction gets zero weights (its hidden state is exactly 0) and the bridge /
+  upper-layer input matrices are zero-extended from ``H`` to ``2H`` columns;
+* layers above the first: one weight image + workspace each (``sad_rnn_layer``), input = the per-step
+  outputs of the layer below; nn.LSTM's inter-layer dropout (classifier copy, training mode) uses masks drawn
+  here.
+
+The shipped configuration (LSTM, bidirectional, one layer) passes its parameters through untouched and is
+the only one that runs the persistent recurrence kernels.
+
+The submodules (``nn.Embedding``, ``nn.LSTM`` / ``nn.GRU``, ``nn.Linear``) exist only as PARAMETER HOLDERS so
 that ``named_parameters()`` filtering, ``requires_grad`` freezing, ``clip_grad_norm_`` and the
 optimizers behave exactly as with the reference; they are constructed in the
 reference's order, so seeding gives the same initial values.  Their ``forward`` is never called:
@@ -21,6 +37,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as Fn
+from . import lib as _lib
 
 
 class _SelfAttnBase(nn.Module):
@@ -35,21 +52,23 @@ class _SelfAttnBase(nn.Module):
         self.mask_id = getattr(config, "mask_id", None)
         self.hidden_size = config.hidden_size
         self.dropout_p = float(getattr(config, "dropout", 0.0)) if self._flavour == "classifier" else 0.0
-        if self.cell != "LSTM" or not self.bidirectional or num_layers != 1:
-            # GRU / uni-directional / multi-layer variants are not on the hot path.
-            raise NotImplementedError(
-                "sad_amd implements the shipped configuration only: cell=LSTM, enc_bidirectional=True, "
-                "enc_num_layers=1 (got cell=%s bidirectional=%s layers=%d)" % (self.cell, self.bidirectional, num_layers))
+        assert self.cell == "LSTM" or self.cell == "GRU"
+        if not 1 <= num_layers <= 1 + _lib.MAX_UPPER_LAYERS:
+            raise ValueError("enc_num_layers must be 1..%d, got %d" % (1 + _lib.MAX_UPPER_LAYERS, num_layers))
+        self.num_layers = num_layers
+        D = 2 if self.bidirectional else 1
 
         # parameter holders, created in the reference's order (transfer/models.py:770-827)
         self.embedding = nn.Embedding.from_pretrained(
             torch.FloatTensor(embedding), freeze=config.freeze_embedding, padding_idx=pad_id
         ) if embedding is not None else nn.Embedding(config.vocab_size, config.emb_size, padding_idx=pad_id)
-        self.rnn = nn.LSTM(input_size=self.embedding.embedding_dim, hidden_size=self.hidden_size,
-                           num_layers=1, dropout=0.0, bidirectional=True)
-        self.output_bridge = nn.Linear(2 * self.hidden_size, self.hidden_size)      # dead in forward
-        self.hidden_bridges = nn.ModuleList([nn.Linear(2 * self.hidden_size, self.hidden_size)
-                                             for _ in range(2)])                    # [1] is dead
+        # (inter-layer dropout: classifier copy only, classifier/models.py:108 vs transfer/models.py:783)
+        self.rnn = getattr(nn, self.cell)(input_size=self.embedding.embedding_dim, hidden_size=self.hidden_size,
+                                          num_layers=num_layers, dropout=(0.0 if num_layers == 1 else self.dropout_p),
+                                          bidirectional=self.bidirectional)
+        self.output_bridge = nn.Linear(D * self.hidden_size, self.hidden_size)      # dead in forward
+        self.hidden_bridges = nn.ModuleList([nn.Linear(D * self.hidden_size, self.hidden_size)
+                                             for _ in range(2 if self.cell == "LSTM" else 1)])   # [1] is dead
         if self._flavour == "classifier":
             self.dropout_layer = nn.Dropout(self.dropout_p)
         self.linear_emb = nn.Linear(self.embedding.embedding_dim, self.hidden_size)
@@ -70,28 +89,78 @@ class _SelfAttnBase(nn.Module):
             param.requires_grad = True
 
     # -- packed weights ---------------------------------------------------------------------------
-    def _live(self):
+    def _real(self):
+        """The parameters that reach the logits (everything but output_bridge.* / hidden_bridges.1.*)."""
+        return {k: p for k, p in self.named_parameters()
+                if not (k.startswith("output_bridge.") or k.startswith("hidden_bridges.1."))}
+
+    def _slots4(self, w, hidden_half):
+        """GRU [3H, .] -> the kernels' four gate slots [4H, .]: input half [r, z, n, 0], hidden half [r, z, 0, n]."""
+        if self.cell == "LSTM":
+            return w
+        H = self.hidden_size
+        z = w.new_zeros((H,) + tuple(w.shape[1:]))
+        return torch.cat([w[:2 * H], z, w[2 * H:]], 0) if hidden_half else torch.cat([w, z], 0)
+
+    def _canonical(self):
+        """(the 19 tensors of layer 0, [the 8 rnn.* tensors of every layer above]) in the kernels' canonical
+        layout, built from the real parameters with differentiable torch ops (cat with zeros): the shipped
+        configuration returns its parameters themselves."""
         sd = dict(self.named_parameters())
-        return {k: sd[k] for k in Fn._LIVE_PARAMS}
+        H = self.hidden_size
+
+        def widen(w):            # uni-directional: [., H] -> [., 2H] (the reverse half is exactly zero)
+            return w if self.bidirectional else torch.cat([w, torch.zeros_like(w)], 1)
+
+        layers = []
+        for l in range(self.num_layers):
+            out = {}
+            for sfx in ("", "_reverse"):
+                k = "_l%d%s" % (l, sfx)
+                if sfx and not self.bidirectional:
+                    for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                        out["rnn.%s_l0%s" % (n, sfx)] = torch.zeros_like(out["rnn.%s_l0" % n])
+                    continue
+                w_ih = self._slots4(sd["rnn.weight_ih" + k], False)
+                out["rnn.weight_ih_l0" + sfx] = widen(w_ih) if l > 0 else w_ih
+                out["rnn.weight_hh_l0" + sfx] = self._slots4(sd["rnn.weight_hh" + k], True)
+                out["rnn.bias_ih_l0" + sfx] = self._slots4(sd["rnn.bias_ih" + k], False)
+                out["rnn.bias_hh_l0" + sfx] = self._slots4(sd["rnn.bias_hh" + k], True)
+            layers.append(out)
+        live = dict(layers[0])
+        for k in Fn._LIVE_PARAMS:
+            if k not in live:
+                live[k] = widen(sd[k]) if k == "hidden_bridges.0.weight" else sd[k]
+        return live, layers[1:]
 
     def packed_weights(self):
         """Packed device image of the current parameters; re-packed whenever a live parameter's
         storage or version counter changes (optimizer step, load_state_dict, .to())."""
-        live = self._live()
-        key = tuple((p.data_ptr(), p._version, p.device) for p in live.values())
+        real = self._real()
+        key = tuple((p.data_ptr(), p._version, p.device) for p in real.values())
         if self._pw is None or key != self._pw_key:
-            self._pw = Fn.pack_weights(live)
+            with torch.no_grad():
+                live, upper = self._canonical()
+                self._pw = Fn.pack_weights(live, cell=_lib.CELL_GRU if self.cell == "GRU" else _lib.CELL_LSTM, upper=upper)
             self._pw_key = key
         return self._pw
 
     def _trainable(self):
-        """The live parameters when the call must be differentiable w.r.t. them (classifier training,
-        reference classifier/trainers.py:367-373), else None: the frozen transfer-loop mode
+        """The live parameters (canonical layout) when the call must be differentiable w.r.t. them (classifier
+        training, reference classifier/trainers.py:367-373), else (None, ()): the frozen transfer-loop mode
         (reference transfer/trainers.py:216-223) skips every weight-gradient kernel."""
-        live = self._live()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in live.values()):
-            return live
-        return None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._real().values()):
+            return self._canonical()
+        return None, ()
+
+    def _draw_layer_keep(self, src):
+        """Keep masks of nn.LSTM's inter-layer dropout [T,B,2H] per layer boundary (classifier copy in training
+        mode with enc_num_layers > 1, reference classifier/models.py:108); None otherwise."""
+        if self._flavour != "classifier" or not self.training or self.dropout_p <= 0.0 or self.num_layers == 1:
+            return None
+        B, T = src.shape[0], src.shape[1]
+        return [(torch.rand((T, B, 2 * self.hidden_size), device=src.device) >= self.dropout_p, 1.0 / (1.0 - self.dropout_p))
+                for _ in range(self.num_layers - 1)]
 
     def _run(self, src, src_len, mask, hidden, soft, guard, drop=None, onehot=None):
         if hidden is not None:
@@ -100,8 +169,10 @@ class _SelfAttnBase(nn.Module):
             raise RuntimeError("soft=True expects [B,T,V] soft tokens")
         if not soft and src.dim() != 2:
             raise RuntimeError("soft=False expects [B,T] token ids")
-        return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard, params=self._trainable(),
-                                pad_id=self.embedding.padding_idx, drop=drop, onehot=onehot)
+        params, upper = self._trainable()
+        return Fn.discriminator(src, src_len, mask, self.packed_weights(), guard=guard, params=params,
+                                pad_id=self.embedding.padding_idx, drop=drop, onehot=onehot,
+                                layer_drop=self._draw_layer_keep(src), upper_params=upper)
 
     def _draw_keep(self, src):
         """Inverted-dropout keep mask on the embedded tokens [T,B,E] (classifier copy in training mode,
@@ -122,9 +193,11 @@ class _SelfAttnBase(nn.Module):
             raise RuntimeError("soft=True expects [B,T,V] soft tokens")
         if not soft and src.dim() != 2:
             raise RuntimeError("soft=False expects [B,T] token ids")
+        params, upper = self._trainable()
         return Fn.discriminator_loss(src, src_len, mask, labels, self.packed_weights(),
-                                     guard=self._flavour == "transfer", params=self._trainable(),
-                                     pad_id=self.embedding.padding_idx, drop=self._draw_keep(src))
+                                     guard=self._flavour == "transfer", params=params,
+                                     pad_id=self.embedding.padding_idx, drop=self._draw_keep(src),
+                                     layer_drop=self._draw_layer_keep(src), upper_params=upper)
 
 
 class TransferSelfAttnRNNClassifier(_SelfAttnBase):
@@ -179,3 +252,47 @@ class ClassifierSelfAttnRNNClassifier(_SelfAttnBase):
 # The hot path is the transfer copy (the one embedded in TransferModel as `.classifier`,
 # reference transfer/models.py:961).
 SelfAttnRNNClassifier = TransferSelfAttnRNNClassifier
+
+
+class CNNClassifier(nn.Module):
+    """Drop-in for the reference's CNN metric classifier (reference classifier/models.py:8-73; used as the
+    transfer-accuracy metric, transfer/trainers.py:247-248,523).  Same constructor, state_dict and
+    ``forward(src, soft=False)``.  SURVEY.md §8 f4 scopes its SOFT branch (:53-54): the contraction
+    ``src @ embedding.weight`` runs in libsad's K1 / K1' kernels (``functional.soft_embedding``, differentiable
+    in both operands, bf16 MFMA inputs with fp32 accumulation).  The convolution stack behind it is the eval
+    metric's own model (out of scope) and stays on torch's library ops."""
+
+    def __init__(self, config, embedding=None):
+        super().__init__()
+        pad_id = getattr(config, "pad_id", 0)
+        dropout = getattr(config, "dropout", 0.0)
+        self.num_kernels_each_size = config.num_kernels_each_size
+        self.kernel_sizes = config.kernel_sizes
+        hidden_size = config.num_kernels_each_size * len(config.kernel_sizes)
+        self.embedding = nn.Embedding.from_pretrained(
+            torch.FloatTensor(embedding), freeze=config.freeze_embedding, padding_idx=pad_id
+        ) if embedding is not None else nn.Embedding(config.vocab_size, config.emb_size, padding_idx=pad_id)
+        self.cnns = nn.ModuleList([nn.Conv2d(1, config.num_kernels_each_size, (ks, config.emb_size))
+                                   for ks in config.kernel_sizes])
+        self.ffn = nn.Linear(hidden_size, config.num_labels)
+        self.dropout_layer = nn.Dropout(dropout)
+        self.device = config.device
+
+    def forward(self, src, soft=False):
+        if soft:
+            if src.dim() != 3:
+                raise RuntimeError("soft=True expects [B,T,V] soft tokens")
+            embedded = Fn.soft_embedding(src, self.embedding.weight)      # classifier/models.py:54
+        else:
+            embedded = self.embedding(src)
+        embedded = self.dropout_layer(embedded)
+        outputs = []
+        for i, cnn in enumerate(self.cnns):
+            if self.kernel_sizes[i] <= embedded.shape[1]:
+                temp = torch.relu(cnn(embedded.unsqueeze(1)).squeeze(3))
+                temp = torch.nn.functional.max_pool1d(temp, temp.size(2)).squeeze(2)
+            else:
+                temp = torch.zeros(embedded.shape[0], self.num_kernels_each_size, device=embedded.device,
+                                   dtype=embedded.dtype)
+            outputs.append(temp)
+        return self.ffn(torch.cat(outputs, dim=1))

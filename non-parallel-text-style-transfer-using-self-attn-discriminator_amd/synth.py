@@ -14,19 +14,23 @@ import numpy as np
 GATES = 4  # torch LSTM gate order: i, f, g, o  (reference transfer/models.py:779-785 -> nn.LSTM)
 
 
-def param_shapes(V, E, H, L=2):
-    """Ordered name -> shape map; the order is the reference module's ``state_dict()`` order."""
+def param_shapes(V, E, H, L=2, cell="LSTM", bidirectional=True, layers=1):
+    """Ordered name -> shape map; the order is the reference module's ``state_dict()`` order
+    (variants: reference classifier/models.py:102-124)."""
     s = OrderedDict()
+    G = GATES if cell == "LSTM" else 3          # GRU gate order: r, z, n
+    D = 2 if bidirectional else 1
     s["embedding.weight"] = (V, E)
-    for sfx in ("", "_reverse"):
-        s["rnn.weight_ih_l0" + sfx] = (GATES * H, E)
-        s["rnn.weight_hh_l0" + sfx] = (GATES * H, H)
-        s["rnn.bias_ih_l0" + sfx] = (GATES * H,)
-        s["rnn.bias_hh_l0" + sfx] = (GATES * H,)
-    s["output_bridge.weight"] = (H, 2 * H)
+    for l in range(layers):
+        for sfx in ("", "_reverse")[:D]:
+            s["rnn.weight_ih_l%d%s" % (l, sfx)] = (G * H, E if l == 0 else D * H)
+            s["rnn.weight_hh_l%d%s" % (l, sfx)] = (G * H, H)
+            s["rnn.bias_ih_l%d%s" % (l, sfx)] = (G * H,)
+            s["rnn.bias_hh_l%d%s" % (l, sfx)] = (G * H,)
+    s["output_bridge.weight"] = (H, D * H)
     s["output_bridge.bias"] = (H,)
-    for i in range(2):
-        s["hidden_bridges.%d.weight" % i] = (H, 2 * H)
+    for i in range(2 if cell == "LSTM" else 1):
+        s["hidden_bridges.%d.weight" % i] = (H, D * H)
         s["hidden_bridges.%d.bias" % i] = (H,)
     s["linear_emb.weight"] = (H, E)
     s["linear_emb.bias"] = (H,)
@@ -44,12 +48,14 @@ DEAD_PARAMS = ("output_bridge.weight", "output_bridge.bias",
                "hidden_bridges.1.weight", "hidden_bridges.1.bias")
 
 
-def make_params(V, E, H, L=2, seed=0, emb_std=1.0, pad_id=0, dtype=np.float32):
+def make_params(V, E, H, L=2, seed=0, emb_std=1.0, pad_id=0, dtype=np.float32, cell="LSTM", bidirectional=True,
+                layers=1):
     """torch-default-like magnitudes: embedding ~ N(0, emb_std) with a zero pad row, every other
     tensor ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (LSTM: 1/sqrt(H))."""
     rs = np.random.RandomState(seed)
     out = OrderedDict()
-    for name, shape in param_shapes(V, E, H, L).items():
+    shapes = param_shapes(V, E, H, L, cell, bidirectional, layers)
+    for name, shape in shapes.items():
         if name == "embedding.weight":
             w = rs.standard_normal(shape) * emb_std
             w[pad_id] = 0.0
@@ -58,7 +64,7 @@ def make_params(V, E, H, L=2, seed=0, emb_std=1.0, pad_id=0, dtype=np.float32):
                 k = 1.0 / np.sqrt(H)
             elif name.endswith(".bias"):
                 # fan_in of the matching weight
-                k = 1.0 / np.sqrt(param_shapes(V, E, H, L)[name[:-4] + "weight"][1])
+                k = 1.0 / np.sqrt(shapes[name[:-4] + "weight"][1])
             else:
                 k = 1.0 / np.sqrt(shape[1])
             w = rs.uniform(-k, k, size=shape)

@@ -1,0 +1,184 @@
+"""SURVEY.md §8 f4 on the GPU: GRU / uni-directional / multi-layer discriminators (reference
+classifier/models.py:102-124,243-260) and the CNN metric classifier's soft branch (:53-54) through the
+drop-in modules, against fixtures recorded from the reference itself (tools/gen_golden.py, float64) and
+against the generalized oracle on a ragged Yelp-dims batch.  Tolerances: bf16 MFMA inputs, fp32 accumulation."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import sad_oracle as O
+from sad_amd import synth
+from tests.util import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD, TOL_DS, TOL_WGRAD = 2e-2, 3e-2, 3e-2
+VARIANT_TAGS = ["gru_bi", "lstm_uni", "gru_uni", "lstm_bi_l2", "gru_bi_l2", "lstm_uni_l3"]
+
+
+def _cfg(hdr, dropout=0.0):
+    return SimpleNamespace(cell=hdr["cell"], enc_bidirectional=hdr["bidirectional"], pad_id=0, dropout=dropout,
+                           enc_num_layers=hdr["layers"], hidden_size=hdr["H"], vocab_size=hdr["V"], emb_size=hdr["E"],
+                           num_labels=hdr["L"], freeze_embedding=False, device="cuda:0", mask_id=None)
+
+
+def _module(which, hdr, params, dropout=0.0):
+    import torch
+    from sad_amd import classifier_models, transfer_models
+    mod = transfer_models if which == "transfer" else classifier_models
+    m = mod.SelfAttnRNNClassifier(_cfg(hdr, dropout))
+    assert list(m.state_dict().keys()) == list(params.keys())          # a reference checkpoint loads unchanged
+    m.load_state_dict({k: torch.from_numpy(v.astype(np.float32)) for k, v in params.items()})
+    return m.to("cuda:0")
+
+
+@pytest.mark.parametrize("tag", VARIANT_TAGS)
+def test_variant_golden(tag):
+    import torch
+    hdr, d, params, grads = load_golden("variant_%s_f64.npz" % tag)
+    B = len(d["labels"])
+    m = _module("transfer", hdr, params)
+    S = torch.from_numpy(d["S"].astype(np.float32)).cuda().requires_grad_(True)      # [T,B,V] time-major
+    mask = torch.from_numpy(d["mask"].copy()).cuda()
+    lab = torch.from_numpy(d["labels"]).cuda()
+    logits, w = m(S.transpose(0, 1), torch.from_numpy(d["lengths"]).to(torch.int16), mask, soft=True)
+    loss = torch.nn.functional.cross_entropy(logits, lab, reduction="none")
+    (loss.sum() / B).backward()
+    assert np.array_equal(mask.cpu().numpy(), d["mask_after"])
+    assert relerr(logits.detach().cpu().numpy(), d["logits"]) < TOL_FWD
+    assert relerr(w.detach().cpu().numpy(), d["weights"]) < TOL_FWD
+    assert relerr(loss.detach().cpu().numpy(), d["loss"]) < TOL_FWD
+    dS = S.grad.cpu().numpy()
+    assert relerr(dS, d["dS"]) < TOL_DS
+    for b, ln in enumerate(d["lengths"]):
+        assert np.all(dS[ln:, b] == 0)
+    got = {k: p.grad for k, p in m.named_parameters()}
+    for k in hdr["none_grads"]:
+        assert got[k] is None, k
+    errs = {}
+    for k, g in grads.items():
+        assert got[k] is not None and tuple(got[k].shape) == g.shape, k
+        # (floor for the two cancelling sums: d output_layer.bias = sum_b (p_b - y_b) / B and d linear_emb.bias =
+        # sum over tokens of dKk are ~2e-3 here while their terms are ~1e-1, so the bf16-level error of the logits
+        # / of dKk shows up at 1e-4 absolute; below the floor the comparison is absolute)
+        errs[k] = relerr(got[k].cpu().numpy(), g, floor=1e-2 if k in ("output_layer.bias", "linear_emb.bias") else 1e-3)
+    print("\n%s wgrad errors: %s" % (tag, {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]}))
+    assert max(errs.values()) < TOL_WGRAD, errs
+    # frozen mode (the transfer loop): same outputs and dS, no parameter gradients
+    for p in m.parameters():
+        p.requires_grad = False
+        p.grad = None
+    S2 = torch.from_numpy(d["S"].astype(np.float32)).cuda().requires_grad_(True)
+    mask = torch.from_numpy(d["mask"].copy()).cuda()
+    loss2, logits2, _ = m.loss(S2.transpose(0, 1), torch.from_numpy(d["lengths"]), mask, lab)
+    (loss2.sum() / B).backward()
+    assert torch.equal(logits2, logits.detach())
+    assert torch.equal(S2.grad, S.grad)
+    # classifier copy, hard tokens, eval mode
+    mc = _module("classifier", hdr, params).eval()
+    keep = d["cls_keep"]
+    ids = torch.from_numpy(d["ids"][keep]).cuda()
+    with torch.no_grad():
+        lg, w2 = mc(ids, torch.from_numpy(d["lengths"][keep]), ids == 0)
+    assert relerr(lg.cpu().numpy(), d["cls_logits"]) < TOL_FWD
+    assert relerr(w2.cpu().numpy(), d["cls_weights"]) < TOL_FWD
+
+
+@pytest.mark.parametrize("cell,bi,layers", [("GRU", True, 1), ("LSTM", False, 2), ("GRU", True, 2)])
+def test_variant_yelp_dims_vs_oracle(cell, bi, layers):
+    """Yelp dims (V=9353, E=300, H=512), ragged batch of 48: outputs, dS and parameter gradients against the
+    float64 oracle (which tests/test_oracle_golden.py::test_variant_oracle pins to the reference)."""
+    import torch
+    V, E, H, B, T = 9353, 300, 512, 48, 19
+    hdr = dict(cell=cell, bidirectional=bi, layers=layers, V=V, E=E, H=H, L=2)
+    params = synth.make_params(V, E, H, seed=31, cell=cell, bidirectional=bi, layers=layers)
+    lengths = synth.make_lengths(B, T, seed=2, lo=2)
+    mask = synth.transfer_mask(lengths, T)
+    labels = synth.make_labels(B, seed=5)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=8, kind="dense")                 # [T,B,V]
+    m = _module("transfer", hdr, params)
+    St = torch.from_numpy(S).cuda().requires_grad_(True)
+    mk = torch.from_numpy(mask.copy()).cuda()
+    lab = torch.from_numpy(labels).cuda()
+    loss, logits, w = m.loss(St.transpose(0, 1), torch.from_numpy(lengths), mk, lab)
+    (loss.sum() / B).backward()
+    p64 = O.cast_params(params, np.float64)
+    S_bt = np.ascontiguousarray(S.transpose(1, 0, 2)).astype(np.float64)
+    f = O.forward(p64, S_bt, lengths, mask.copy(), True, labels=labels)
+    b = O.backward(p64, f["cache"], O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B)), want_param_grads=True)
+    assert relerr(logits.detach().cpu().numpy(), f["logits"]) < TOL_FWD
+    assert relerr(w.detach().cpu().numpy(), f["weights"]) < TOL_FWD
+    assert relerr(St.grad.cpu().numpy(), b["dS"].transpose(1, 0, 2)) < TOL_DS
+    got = {k: p.grad for k, p in m.named_parameters()}
+    for k, g in b["grads"].items():
+        assert relerr(got[k].cpu().numpy(), g, floor=1e-3) < TOL_WGRAD, k
+
+
+def test_multilayer_interlayer_dropout_vs_oracle():
+    """Classifier copy in training mode with enc_num_layers=2 and dropout: nn.LSTM's inter-layer dropout
+    (reference classifier/models.py:108) plus the dropout on the embedded tokens (:217), with the keep masks
+    this package drew handed to the oracle."""
+    import torch
+    from sad_amd import functional as Fn
+    V, E, H, B, T = 57, 20, 24, 7, 11
+    hdr = dict(cell="LSTM", bidirectional=True, layers=2, V=V, E=E, H=H, L=2)
+    params = synth.make_params(V, E, H, seed=41, dtype=np.float64, layers=2)
+    lengths = np.array([11, 9, 8, 6, 4, 3, 3], dtype=np.int32)
+    ids = synth.make_token_ids(B, T, V, lengths, seed=4)
+    labels = synth.make_labels(B, seed=6)
+    m = _module("classifier", hdr, params, dropout=0.25).train()
+    drawn = {}
+    orig_keep, orig_layer = m._draw_keep, m._draw_layer_keep
+
+    def keep_hook(src):
+        drawn["drop"] = orig_keep(src)
+        return drawn["drop"]
+
+    def layer_hook(src):
+        drawn["layer"] = orig_layer(src)
+        return drawn["layer"]
+
+    m._draw_keep, m._draw_layer_keep = keep_hook, layer_hook
+    idt = torch.from_numpy(ids).cuda()
+    logits, w = m(idt, torch.from_numpy(lengths), idt == 0)
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(labels).cuda()).backward()
+    keep, scale = drawn["drop"]
+    drop = (keep.cpu().numpy().transpose(1, 0, 2), scale)                                  # oracle is batch-major
+    layer_drop = [(k.cpu().numpy().transpose(1, 0, 2), s) for k, s in drawn["layer"]]
+    assert 0.6 < layer_drop[0][0].mean() < 0.9
+    cm = synth.classifier_mask(ids == 0)
+    f = O.forward(params, ids, lengths, cm, False, labels=labels, guard=False, drop=drop, layer_drop=layer_drop)
+    b = O.backward(params, f["cache"], O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B)), want_param_grads=True)
+    assert relerr(logits.detach().cpu().numpy(), f["logits"]) < TOL_FWD
+    assert relerr(w.detach().cpu().numpy(), f["weights"]) < TOL_FWD
+    got = {k: p.grad for k, p in m.named_parameters()}
+    for k, g in b["grads"].items():
+        assert relerr(got[k].cpu().numpy(), g, floor=1e-3) < TOL_WGRAD, k
+
+
+def test_cnn_soft_path_golden():
+    """CNN metric classifier (reference classifier/models.py:8-73): soft branch through libsad's soft-embedding
+    kernels, logits / d(soft tokens) / parameter gradients against the reference's own float64 run."""
+    import torch
+    from sad_amd import classifier_models
+    hdr, d, params, grads = load_golden("cnn_soft_f64.npz")
+    cfg = SimpleNamespace(pad_id=0, dropout=0.0, num_kernels_each_size=hdr["num_kernels_each_size"],
+                          kernel_sizes=hdr["kernel_sizes"], vocab_size=hdr["V"], emb_size=hdr["E"], num_labels=hdr["L"],
+                          freeze_embedding=False, device="cuda:0")
+    m = classifier_models.CNNClassifier(cfg)
+    assert list(m.state_dict().keys()) == list(params.keys())
+    m.load_state_dict({k: torch.from_numpy(v.astype(np.float32)) for k, v in params.items()})
+    m.to("cuda:0").eval()
+    S = torch.from_numpy(d["S"].astype(np.float32)).cuda().requires_grad_(True)         # [B,T,V]
+    logits = m(S, soft=True)
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(d["labels"]).cuda()).backward()
+    assert relerr(logits.detach().cpu().numpy(), d["logits"]) < TOL_FWD
+    assert relerr(S.grad.cpu().numpy(), d["dS"]) < TOL_DS
+    got = {k: p.grad for k, p in m.named_parameters()}
+    for k, g in grads.items():
+        assert relerr(got[k].cpu().numpy(), g, floor=1e-3) < TOL_WGRAD, k
+    assert got["cnns.3.weight"] is None                     # kernel size above T never runs (:62,:69)
+    with torch.no_grad():
+        hard = m(torch.from_numpy(d["ids"]).cuda())
+    assert relerr(hard.cpu().numpy(), d["hard_logits"]) < 1e-4

@@ -131,3 +131,36 @@ def test_classifier_dropout_training_step():
     assert len(grads) == 19
     for k, g in grads.items():
         assert relerr(b["grads"][k], g, floor=1e-3) < 1e-10, k
+
+
+VARIANT_TAGS = ["gru_bi", "lstm_uni", "gru_uni", "lstm_bi_l2", "gru_bi_l2", "lstm_uni_l3"]
+
+
+@pytest.mark.parametrize("tag", VARIANT_TAGS)
+def test_variant_oracle(tag):
+    """GRU / uni-directional / multi-layer discriminators (reference
+    classifier/models.py:102-124,243-260) — the generalized oracle against the reference's outputs, dS and
+    every parameter gradient."""
+    hdr, d, params, grads = load_golden("variant_%s_f64.npz" % tag)
+    assert O.variant(params) == (hdr["cell"], 2 if hdr["bidirectional"] else 1, hdr["layers"])
+    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2))
+    mask = d["mask"].copy()
+    f = O.forward(params, S_bt, d["lengths"], mask, True, labels=d["labels"])
+    assert np.array_equal(mask, d["mask_after"])
+    assert relerr(f["logits"], d["logits"]) < 1e-12
+    assert relerr(f["weights"], d["weights"]) < 1e-12
+    assert relerr(f["loss"], d["loss"]) < 1e-12
+    B = len(d["labels"])
+    dlog = O.ce_dlogits(f["logits"], d["labels"], np.full((B,), 1.0 / B))
+    b = O.backward(params, f["cache"], dlog, want_param_grads=True)
+    assert relerr(b["dS"].transpose(1, 0, 2), d["dS"]) < 1e-11
+    dead = {k for k in params if k.startswith("output_bridge.") or k.startswith("hidden_bridges.1.")}
+    assert set(hdr["none_grads"]) == dead
+    for k, g in grads.items():
+        assert relerr(b["grads"][k], g, floor=1e-3) < 1e-10, k
+    assert set(grads) | dead == set(params)
+    keep = d["cls_keep"]
+    ids = d["ids"][keep]
+    f2 = O.forward(params, ids, d["lengths"][keep], synth.classifier_mask(ids == 0), False, guard=False)
+    assert relerr(f2["logits"], d["cls_logits"]) < 1e-12
+    assert relerr(f2["weights"], d["cls_weights"]) < 1e-12

@@ -31,16 +31,16 @@ import torch.nn.functional as F  # noqa: E402
 from sad_amd import synth  # noqa: E402
 
 
-def ref_config(V, E, H, L=2, dropout=0.0):
-    return SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=dropout,
-                           enc_num_layers=1, hidden_size=H, vocab_size=V, emb_size=E,
+def ref_config(V, E, H, L=2, dropout=0.0, cell="LSTM", bidirectional=True, layers=1):
+    return SimpleNamespace(cell=cell, enc_bidirectional=bidirectional, pad_id=0, dropout=dropout,
+                           enc_num_layers=layers, hidden_size=H, vocab_size=V, emb_size=E,
                            num_labels=L, freeze_embedding=False, device="cpu", mask_id=None)
 
 
-def build_ref(which, V, E, H, params, dtype, dropout=0.0):
+def build_ref(which, V, E, H, params, dtype, dropout=0.0, **variant):
     import importlib
     mod = importlib.import_module("%s.models" % which)   # /root/reference/{transfer,classifier}/models.py
-    m = mod.SelfAttnRNNClassifier(ref_config(V, E, H, dropout=dropout))
+    m = mod.SelfAttnRNNClassifier(ref_config(V, E, H, dropout=dropout, **variant))
     sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
     assert list(m.state_dict().keys()) == list(params.keys()), "state_dict layout drifted"
     m = m.to(dtype)          # cast first: load_state_dict copies INTO the existing dtype
@@ -257,10 +257,80 @@ def yelp_hard_case(outdir):
     save(os.path.join(outdir, "yelp_hard_b64.npz"), hdr, **arrs)
 
 
+VARIANTS = (          # tag, cell, bidirectional, layers   (classifier/models.py:102-124)
+    ("gru_bi", "GRU", True, 1),
+    ("lstm_uni", "LSTM", False, 1),
+    ("gru_uni", "GRU", False, 1),
+    ("lstm_bi_l2", "LSTM", True, 2),
+    ("gru_bi_l2", "GRU", True, 2),
+    ("lstm_uni_l3", "LSTM", False, 3),
+)
+
+
+def variant_cases(outdir):
+    """GRU / uni-directional / multi-layer discriminators: the transfer copy on dense soft tokens (outputs,
+    dS, every parameter gradient) and the classifier copy on hard tokens in eval mode, float64."""
+    V, E, H, B, T = 41, 10, 8, 6, 9
+    lengths = np.array([9, 7, 5, 3, 3, 2], dtype=np.int32)
+    labels = synth.make_labels(B, seed=3)
+    mask = synth.transfer_mask(lengths, T)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=5, kind="dense", dtype=np.float64)
+    ids = synth.make_token_ids(B, T, V, lengths, seed=9)
+    for tag, cell, bi, layers in VARIANTS:
+        var = dict(cell=cell, bidirectional=bi, layers=layers)
+        params = synth.make_params(V, E, H, seed=13, dtype=np.float64, **var)
+        m = build_ref("transfer", V, E, H, params, torch.float64, **var)
+        o = run_transfer_copy(m, S, lengths, mask, labels, True, torch.float64)
+        arrs = dict(S=S, ids=ids, lengths=lengths, mask=mask, labels=labels, logits=o["logits"], weights=o["weights"],
+                    loss=o["loss"], mask_after=o["mask_after"], dS=o["dS"])
+        for k, g in o["grads"].items():
+            arrs["grad:" + k] = g
+        for k, v in params.items():
+            arrs["param:" + k] = v
+        keep = lengths >= 3
+        mc = build_ref("classifier", V, E, H, params, torch.float64, **var)
+        lg, w = mc(torch.from_numpy(ids[keep]), torch.from_numpy(lengths[keep]), torch.from_numpy(ids[keep] == 0))
+        arrs.update(cls_keep=keep, cls_logits=lg.detach().numpy(), cls_weights=w.detach().numpy())
+        hdr = dict(case="variant_%s_f64" % tag, V=V, E=E, H=H, B=B, T=T, L=2, param_seed=13, s_seed=5, id_seed=9,
+                   label_seed=3, none_grads=o["none_grads"], **var, **versions())
+        save(os.path.join(outdir, "variant_%s_f64.npz" % tag), hdr, **arrs)
+
+
+def cnn_case(outdir):
+    """CNN metric classifier (classifier/models.py:8-73), soft and hard branch, eval mode, float64, with
+    d(soft tokens) and the parameter gradients of the mean CE loss."""
+    import importlib
+    mod = importlib.import_module("classifier.models")
+    V, E, B, T, L = 41, 10, 5, 9, 2
+    cfg = SimpleNamespace(pad_id=0, dropout=0.0, num_kernels_each_size=3, kernel_sizes=[2, 3, 4, 11], vocab_size=V,
+                          emb_size=E, num_labels=L, freeze_embedding=False, device="cpu")
+    torch.manual_seed(77)
+    m = mod.CNNClassifier(cfg).to(torch.float64)
+    m.eval()
+    lengths = np.full((B,), T, dtype=np.int32)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=15, kind="dense", dtype=np.float64)     # [T,B,V]
+    Sb = torch.from_numpy(np.ascontiguousarray(S.transpose(1, 0, 2))).requires_grad_(True)    # [B,T,V]
+    labels = synth.make_labels(B, seed=3)
+    logits = m(Sb, soft=True)
+    loss = F.cross_entropy(logits, torch.from_numpy(labels))
+    loss.backward()
+    ids = synth.make_token_ids(B, T, V, lengths, seed=9)
+    hard = m(torch.from_numpy(ids))
+    arrs = dict(S=Sb.detach().numpy(), labels=labels, logits=logits.detach().numpy(), dS=Sb.grad.numpy(), ids=ids,
+                hard_logits=hard.detach().numpy())
+    for k, q in m.named_parameters():
+        arrs["param:" + k] = q.detach().numpy()
+        if q.grad is not None:               # the kernel size above T never runs (classifier/models.py:62,69)
+            arrs["grad:" + k] = q.grad.numpy()
+    hdr = dict(case="cnn_soft_f64", V=V, E=E, B=B, T=T, L=L, num_kernels_each_size=3, kernel_sizes=[2, 3, 4, 11],
+               torch_seed=77, s_seed=15, id_seed=9, label_seed=3, **versions())
+    save(os.path.join(outdir, "cnn_soft_f64.npz"), hdr, **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default=None, help="regenerate one family: dropout")
+    ap.add_argument("--only", default=None, help="regenerate one family: dropout | variants")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.manual_seed(0)
@@ -268,10 +338,16 @@ def main():
     if a.only == "dropout":
         dropout_case(a.out)
         return
+    if a.only == "variants":
+        variant_cases(a.out)
+        cnn_case(a.out)
+        return
     tiny_cases(a.out)
     dropout_case(a.out)
     yelp_soft_cases(a.out)
     yelp_hard_case(a.out)
+    variant_cases(a.out)
+    cnn_case(a.out)
 
 
 if __name__ == "__main__":

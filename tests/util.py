@@ -163,11 +163,12 @@ def stage_errors(ws, f, b, H, E):
         return float(np.max(np.abs(a - r)) / max(np.max(np.abs(r)), 1e-30)) if r.size else 0.0
 
     errs["X"] = rel(ws["X"][:, :, :E], c["X"].transpose(1, 0, 2), act)
-    for d, key in ((0, "cf"), (1, "cb")):
-        errs["G%d" % d] = rel(ws["G"][:, :, d, :][:, :, gc], c[key]["gates"], act)
-        errs["CS%d" % d] = rel(ws["CS"][:, :, d, :H], c[key]["c"], act)
-        g = c[key]["gates"]
-        h = g[:, :, 3 * H:4 * H] * np.tanh(c[key]["c"])
+    for d in (0, 1):
+        cd = c["rnn"][0]["dirs"][d]                              # layer 0, direction d
+        errs["G%d" % d] = rel(ws["G"][:, :, d, :][:, :, gc], cd["gates"], act)
+        errs["CS%d" % d] = rel(ws["CS"][:, :, d, :H], cd["c"], act)
+        g = cd["gates"]
+        h = g[:, :, 3 * H:4 * H] * np.tanh(cd["c"])
         errs["HS%d" % d] = rel(ws["HS"][:, :, d, :H], h, act)
     att = ~c["mask"].T                                           # [T,B] attention-active
     errs["KK"] = rel(ws["KK"][:, :, :H], c["Kk"].transpose(1, 0, 2), att | act)

@@ -173,10 +173,14 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctiles = Gp / LF_BN, rtiles = (B + LF_BM - 1) / LF_BM, groups = rtiles * 2;
     int group, ct;
-    if (groups % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only): keep a group on one XCD
+    if ((gridDim.x / ctiles) % 8 == 0) {
+        // blocks b, b+8, ... share an XCD (speed only): keep a group on one XCD, so that its hand-offs are served
+        // by that XCD's L2.  The host pads the grid to a multiple of 8 groups when that still fits the device;
+        // the workgroups of the padding leave at once.
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         group = xcd + 8 * (slot / ctiles);
         ct = slot % ctiles;
+        if (group >= groups) return;
     } else {
         group = blockIdx.x / ctiles;
         ct = blockIdx.x % ctiles;
@@ -422,10 +426,11 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ctiles = Hp / LB_BN, rtiles = (B + LB_BM - 1) / LB_BM, groups = rtiles * 2;
     int group, ct;
-    if (groups % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only)
+    if ((gridDim.x / ctiles) % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only; see the forward kernel)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         group = xcd + 8 * (slot / ctiles);
         ct = slot % ctiles;
+        if (group >= groups) return;
     } else {
         group = blockIdx.x / ctiles;
         ct = blockIdx.x % ctiles;

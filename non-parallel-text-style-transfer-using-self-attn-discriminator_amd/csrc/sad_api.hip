@@ -364,13 +364,20 @@ bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
     if (s.cell != SAD_CELL_LSTM) return false;   // the GRU runs the per-step kernels
     if (s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
     if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
-    *grid = 2 * ceil_div(s.B, LF_BM) * (s.Gp / LF_BN);
+    // groups padded to a multiple of 8 (one XCD per group, see the kernel) when that still fits
+    const int groups = 2 * ceil_div(s.B, LF_BM), ctiles = s.Gp / LF_BN;
+    *grid = ceil_to(groups, 8) * ctiles;
+    if (persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256)) return true;
+    *grid = groups * ctiles;
     return persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256);
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     if (s.cell != SAD_CELL_LSTM) return false;
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
-    *grid = 2 * ceil_div(s.B, LB_BM) * (s.Hp / LB_BN);
+    const int groups = 2 * ceil_div(s.B, LB_BM), ctiles = s.Hp / LB_BN;
+    *grid = ceil_to(groups, 8) * ctiles;
+    if (persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512)) return true;
+    *grid = groups * ctiles;
     return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512);
 }
 // fp16 activated gates (SAD_WS_GA) are written by the persistent forward recurrence and read by the

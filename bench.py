@@ -171,7 +171,7 @@ def kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits, weights):
         ("K1 soft-embedding fwd (k_tile_list + k_softemb_fwd_sk + k_softemb_fwd_fix)", "mfma+hbm",
          lambda: L.sad_softemb_fwd(D, p(pw.buf), p(S), kind, V, B * V, p(ws.buf), st()),
          2.0 * rows * V * E, rows * V * esz + M * Ep * 2),
-        ("K2a+K3 in-projection fwd (k_inproj_fwd_rs2)", "mfma",
+        ("K2a+K3 in-projection fwd (k_inproj_fwd_rs3)", "mfma",
          lambda: L.sad_inproj_fwd(D, p(pw.buf), p(ws.buf), st()),
          2.0 * rows * E * 9 * H, rows * Ep * 2 + rows * (2 * Gp + Hp) * 4),
         ("K2b LSTM recurrence fwd (k_lstm_fwd_persist2)", "latency",

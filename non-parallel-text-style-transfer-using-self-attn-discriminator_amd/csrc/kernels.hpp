@@ -1878,6 +1878,12 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
 
     if (wave >= 10) {
         // -------------------------------------- store waves --------------------------------------
+        // (Measured, round 2: with V = 9353 a row starts at an arbitrary 2-byte offset, the 128-byte row segment
+        // of a tile straddles 64-byte blocks that the next tile completes an iteration later, and the two partial
+        // writes reach HBM separately: WRITE_SIZE = 1.5 x the tensor, 276 us against 187 us for V = 9344.
+        // Re-aligning the segments here — funnel of two LDS chunks per lane plus a carry strip — cost more in LDS
+        // reads (the kernel runs at the LDS read rate of its compute waves) than the aligned stores gave back:
+        // 342 us.  Callers that own the allocation pad the row pitch instead: producer.SoftTokenAssembler.)
         const int ls = tid - 640;
         long long obase[16];
         bool rok[16];
@@ -2035,79 +2041,16 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
     K1P_OUT2("compute: -, MFMA + LDS write, barrier")
 }
 
-// K2a + K3, A-stationary, with the output tile turned through a wave-private LDS scratch: the
-// accumulator layout gives 16-byte pieces of 16 different rows per quarter wave; after the turn a
-// store instruction writes full 256-byte row segments of 4 rows.  No extra workgroup barrier: a
-// wave's LDS operations execute in program order.
-template <int KS>
-__global__ __launch_bounds__(512) void k_inproj_fwd_rs2(Shape s, const bf16raw* __restrict__ X,
-                                                       const unsigned char* __restrict__ need,
-                                                       const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
-                                                       float* __restrict__ G, float* __restrict__ Kk, int nt_per) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
-    unsigned char* Bs = ip_lds;                                          // 2 x 64 * KS * 64 bytes (two W tile buffers)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char* scr = ip_lds + 2 * 64 * KS * 64 + wave * 8192;        // [32 rows][64 cols] fp32, 256-byte rows
-    const int m0 = blockIdx.x * 256;
-    const int ntiles = s.Ncat / 64;
-    const int nt0 = blockIdx.y * nt_per;
-    const int nt1 = nt0 + nt_per < ntiles ? nt0 + nt_per : ntiles;
-    const int M = s.M, G2 = 2 * s.Gp;
-    int mrow[2];
-    int rneed = 0;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        const int m = m0 + wave * 32 + tm * 16 + (lane & 15);
-        mrow[tm] = m;
-        rneed |= (m < M && need[m] != 0) ? 1 : 0;
-    }
-    const bool wave_any = __any(rneed != 0);
-    const int block_any = __syncthreads_or(rneed != 0);
-    if (!block_any) return;
-    // store side: lane -> rows (lane >> 4) + 4 i of the wave's 32, 16-byte chunk lane & 15 of the 256-byte row
-    int srow[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wave * 32 + (lane >> 4) + 4 * i;
-        srow[i] = (m < M && need[m] != 0) ? m : -1;
-    }
-    const int sc = lane & 15;
-    rs_gemm<KS, 2, true>(X, M, mrow, wave_any, block_any, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
-        if (!wave_any) return;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int r = tm * 16 + (lane & 15);
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const int c = tn * 4 + (lane >> 4);
-                *(f32x4*)&scr[r * 256 + ((c ^ (r & 15)) << 4)] = acc[tm][tn];
-            }
-        }
-        const int n = nt * 64 + sc * 4;
-        const f32x4 bias = *(const f32x4*)&bcat[n];
-        float* base = n < G2 ? G + n : Kk + (n - G2);
-        const long long ld = n < G2 ? s.Gld : s.Hp;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = (lane >> 4) + 4 * i;
-            const f32x4 v = *(const f32x4*)&scr[r * 256 + ((sc ^ (r & 15)) << 4)];
-#ifndef SAD_NO_NT_G
-            // written once, read once by the recurrence much later: keep it out of the L2's way
-            if (srow[i] >= 0) __builtin_nontemporal_store(v + bias, (f32x4*)(base + (long long)srow[i] * ld));
-#else
-            if (srow[i] >= 0) *(f32x4*)(base + (long long)srow[i] * ld) = v + bias;
-#endif
-        }
-    });
-}
-
 // K2a + K3 over the COMPACTED list of needed token rows (k_row_lists, list 0), work split evenly:
 // a ragged batch leaves ~45 % of the time-major rows un-needed, and with one workgroup per 256
 // consecutive rows the launch ran at the speed of its full tiles while the workgroups of late time
 // steps idled (128 us at cfg3 for 54 % of the rows).  Here the units (256-row tile of the list, 64-column
 // tile of Wcat) are ordered tile-major and cut into gridDim.x equal contiguous ranges; a workgroup
-// runs the A-stationary GEMM of k_inproj_fwd_rs2 over each (tile, column range) segment of its range
-// (at most a few tiles: the X fragments are re-loaded per segment).  N is split, not K: no partial sums.
+// runs the A-stationary GEMM (rs_gemm) over each (tile, column range) segment of its range (at most a few
+// tiles: the X fragments are re-loaded per segment).  N is split, not K: no partial sums.
+// The output tile is turned through a wave-private LDS scratch: the accumulator layout gives 16-byte pieces
+// of 16 different rows per quarter wave; after the turn a store instruction writes full 256-byte row segments
+// of 4 rows.  No extra workgroup barrier: a wave's LDS operations execute in program order.
 template <int KS>
 __global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* __restrict__ X,
                                                        const int* __restrict__ rows, const int* __restrict__ nrows,

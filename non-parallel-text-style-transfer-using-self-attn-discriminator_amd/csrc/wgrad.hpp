@@ -455,11 +455,18 @@ template <class W, int KIND>
 __global__ __launch_bounds__(W::NT) void k_wgrad_emb(Shape s, const void* __restrict__ src, long long sT, long long sB,
                                                     const bf16raw* __restrict__ DX,
                                                     const int* __restrict__ rows, const int* __restrict__ nrows,
-                                                    float* __restrict__ gemb) {
+                                                    float* __restrict__ gemb, int xcd_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];   // 2 * 64 * (P1 + P2) bytes
     typedef SoftRow<KIND> SR;
     typedef typename SR::Elem Elem;
-    const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
+    // xcd_tiles != 0 (grid x = 8 * xcd_tiles): workgroups b, b+8, ... share an XCD and take NEIGHBOURING vocabulary
+    // tiles.  A tile's 128-byte row segments of S are misaligned (V = 9353), so every line it fetches is half used
+    // and the other half belongs to the neighbouring tile: on one XCD, at the same time, that half comes out of L2
+    // (FETCH_SIZE 2.3 x the needed rows of S with consecutive tiles spread over the eight XCDs).
+    const int tile1 = xcd_tiles ? (int)(blockIdx.x & 7) * xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (xcd_tiles && (int)(blockIdx.x >> 3) >= xcd_tiles) return;
+    const int n10 = tile1 * W::BN1, n20 = blockIdx.y * W::BN2;
+    if (n10 >= s.V) return;
     int j_begin, j_end;
     if (!wgrad_slice(nrows[ROWS_ANY], blockIdx.z, gridDim.z, &j_begin, &j_end)) return;
     const int V = s.V, Ep = s.Ep, B = s.B;

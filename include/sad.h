@@ -79,7 +79,8 @@ typedef struct sad_weights {
  * with its own weight image and workspace, both built by the caller with the dims
  *     {B, T, V = 1, E = 2H, H, L, cell}
  * where only the rnn_* tensors of sad_weights are this layer's (`weight_ih_l<l>` [4H, 2H], ...) and every other
- * tensor is zero.  Calls with upper layers run the per-step recurrence kernels in every layer. */
+ * tensor is zero.  Every layer runs the same recurrence kernels as a one-layer call (persistent when co-resident);
+ * the layers below the last receive the gradient of their per-step outputs from the layer above. */
 #define SAD_MAX_UPPER_LAYERS 7
 typedef struct sad_rnn_layer {
     const void* packed;       /* sad_pack_weights image of this layer */

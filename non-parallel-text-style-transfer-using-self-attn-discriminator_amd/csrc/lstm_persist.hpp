@@ -54,7 +54,7 @@ __device__ __forceinline__ void lp_store16_sc1(bf16raw* p, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 // Activated gates of the persistent recurrences: fp16 records of [unit][i, f, g, o] (SAD_WS_GA).  The
-// values lie in [-1, 1], so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
+// values lie in [-1, 1] (the GRU's fourth slot, W_hn h + b_hn, is O(1)), so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
 // anyway); a lane's 4 units x 4 gates are 32 contiguous bytes.  Halves the gate stores of the forward
 // recurrence (47 us of its 305 at cfg3 were these stores) and the gate loads of the BPTT.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -314,14 +314,28 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
             const f32x4 pi = acc[tm][0], pf = acc[tm][1], pg = acc[tm][2], po = acc[tm][3];
             const f32x4 cprev = creg[tm];     // still zero at a sentence's first step in this direction
             f32x4 c, h;
+            if (s.cell == CELL_GRU) {
+                // slots [r, z, n_input, n_hidden]; the carried state is the fp32 hidden state; the record keeps
+                // [r, z, n, q = W_hn h + b_hn] for the BPTT (same layout as the per-step kernel k_lstm_fwd)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gi[tm][e] = sigmoidf_(pi[e]);
-                gf[tm][e] = sigmoidf_(pf[e]);
-                gg[tm][e] = tanhf_(pg[e]);
-                go[tm][e] = sigmoidf_(po[e]);
-                c[e] = gf[tm][e] * cprev[e] + gi[tm][e] * gg[tm][e];
-                h[e] = go[tm][e] * tanhf_(c[e]);
+                for (int e = 0; e < 4; ++e) {
+                    gi[tm][e] = sigmoidf_(pi[e]);
+                    gf[tm][e] = sigmoidf_(pf[e]);
+                    go[tm][e] = po[e];
+                    gg[tm][e] = tanhf_(pg[e] + gi[tm][e] * po[e]);
+                    c[e] = (1.f - gf[tm][e]) * gg[tm][e] + gf[tm][e] * cprev[e];
+                    h[e] = c[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gi[tm][e] = sigmoidf_(pi[e]);
+                    gf[tm][e] = sigmoidf_(pf[e]);
+                    gg[tm][e] = tanhf_(pg[e]);
+                    go[tm][e] = sigmoidf_(po[e]);
+                    c[e] = gf[tm][e] * cprev[e] + gi[tm][e] * gg[tm][e];
+                    h[e] = go[tm][e] * tanhf_(c[e]);
+                }
             }
             creg[tm] = c;
             hp[tm] = pack_bf16x4(h);
@@ -417,7 +431,8 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                                                          const bf16raw* __restrict__ whhT, const float* __restrict__ G,
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
                                                          bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync,
-                                                         unsigned spin_limit, int withhold) {
+                                                         unsigned spin_limit, int withhold,
+                                                         const bf16raw* __restrict__ DHS, int ldh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
     LB_PROF_ENTRY
@@ -515,6 +530,13 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
             eccarry[tn] = ecp[tn];
             const bool last = dir ? (t == 0) : (t == len - 1);
             if (last) edhf[tn] = *(const f32x4*)&DHFIN[(long long)b * 2 * Hp + dir * Hp + ju[tn]];
+            if (DHS != nullptr) {
+                // gradient of this step's output from the RNN layer above: d(its input)[t][b][dir*H + unit]
+                const bf16raw* q = DHS + ((long long)t * B + b) * ldh + dir * s.H + ju[tn];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ju[tn] + e < s.H) edhf[tn][e] += bf16_to_f32(q[e]);
+            }
         }
         t_carry = (act && tpf >= 0 && tpf < T && len > tpf) ? tpf : -1;
         f32x4 acc[2];
@@ -577,16 +599,31 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                 const f32x4 dh = acc[tn] + edhf[tn];
                 const f32x4 dcin = (tn_ >= 0 && tn_ < T && len > tn_) ? dcreg[tn] : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 zi, zf, zg, zo, dcn;
+                if (s.cell == CELL_GRU) {
+                    // record = [r, z, n, q], ecp = h_prev, the carried register holds dh * z (as in k_lstm_bwd)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float tc = tanhf_(ec[tn][e]);
-                    const float d_o = dh[e] * tc;
-                    const float dct = dcin[e] + dh[e] * ego[tn][e] * (1.f - tc * tc);
-                    zi[e] = dct * egg[tn][e] * egi[tn][e] * (1.f - egi[tn][e]);
-                    zf[e] = dct * ecp[tn][e] * egf[tn][e] * (1.f - egf[tn][e]);
-                    zg[e] = dct * egi[tn][e] * (1.f - egg[tn][e] * egg[tn][e]);
-                    zo[e] = d_o * ego[tn][e] * (1.f - ego[tn][e]);
-                    dcn[e] = dct * egf[tn][e];
+                    for (int e = 0; e < 4; ++e) {
+                        const float dht = dh[e] + dcin[e];
+                        const float r = egi[tn][e], z = egf[tn][e], n = egg[tn][e], q = ego[tn][e];
+                        const float da = dht * (1.f - z) * (1.f - n * n);
+                        zi[e] = da * q * r * (1.f - r);
+                        zf[e] = dht * (ecp[tn][e] - n) * z * (1.f - z);
+                        zg[e] = da;
+                        zo[e] = da * r;
+                        dcn[e] = dht * z;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float tc = tanhf_(ec[tn][e]);
+                        const float d_o = dh[e] * tc;
+                        const float dct = dcin[e] + dh[e] * ego[tn][e] * (1.f - tc * tc);
+                        zi[e] = dct * egg[tn][e] * egi[tn][e] * (1.f - egi[tn][e]);
+                        zf[e] = dct * ecp[tn][e] * egf[tn][e] * (1.f - egf[tn][e]);
+                        zg[e] = dct * egi[tn][e] * (1.f - egg[tn][e] * egg[tn][e]);
+                        zo[e] = d_o * ego[tn][e] * (1.f - ego[tn][e]);
+                        dcn[e] = dct * egf[tn][e];
+                    }
                 }
                 dcreg[tn] = dcn;
                 const f32x4 zz[4] = {zi, zf, zg, zo};

@@ -361,7 +361,6 @@ bool persist_fits(const void* kernel, size_t lds, int grid, int threads) {
 }
 // forward recurrence: half-width workgroups, two per CU
 bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
-    if (s.cell != SAD_CELL_LSTM) return false;   // the GRU runs the per-step kernels
     if (s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
     if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
     // groups padded to a multiple of 8 (one XCD per group, see the kernel) when that still fits
@@ -372,7 +371,6 @@ bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
     return persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256);
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
-    if (s.cell != SAD_CELL_LSTM) return false;
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
     const int groups = 2 * ceil_div(s.B, LB_BM), ctiles = s.Hp / LB_BN;
     *grid = ceil_to(groups, 8) * ctiles;
@@ -561,7 +559,6 @@ struct Ctx {
     const void* packed;
     void* ws;
     hipStream_t st;
-    bool per_step = false;   // multi-layer calls: every layer runs the per-step recurrence kernels (fp32 gates in G)
 };
 
 // K2a + K3: [G | Kk] = X . Wcat^T + bcat
@@ -603,7 +600,7 @@ int run_lstm_fwd(const Ctx& c) {
     bf16raw* Hs = at<bf16raw>(c.ws, c.wl.off[SAD_WS_HS]);
     const bf16raw* whh = at<bf16raw>(c.packed, c.pl.whh);
     int pgrid = 0;
-    if (!c.per_step && lstm_fwd_persist_fits(s, &pgrid)) {
+    if (lstm_fwd_persist_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), c.st, s, lens, whh, G, Cs,
                            Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
@@ -719,7 +716,7 @@ int run_bridge_bwd(const Ctx& c, const Ctx& top) {
 // hand-off counters must be zero (k_attn_bwd of the same call, or run_zero_sync); the timeout words
 // behind them keep what the forward left.
 // `dhs` (bf16 [T*B][ldh], column dir*H + unit, or NULL): gradient of every step's output when a layer above
-// consumed it; only the per-step kernel takes it.
+// consumed it.
 int run_lstm_bwd(const Ctx& c, const bf16raw* dhs = nullptr, int ldh = 0) {
     const Shape& s = c.s;
     const int* lens = at<int>(c.ws, c.wl.off[SAD_WS_LENS]);
@@ -730,12 +727,12 @@ int run_lstm_bwd(const Ctx& c, const bf16raw* dhs = nullptr, int ldh = 0) {
     bf16raw* DZ = at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZ]);
     const bf16raw* whhT = at<bf16raw>(c.packed, c.pl.whhT);
     int pgrid = 0;
-    if (!c.per_step && dhs == nullptr && lstm_bwd_persist_fits(s, &pgrid)) {
+    if (lstm_bwd_persist_fits(s, &pgrid)) {
         hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), c.st, s, lens, whhT, G,
                            Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
-                           g_withhold_bwd.load(std::memory_order_relaxed));
+                           g_withhold_bwd.load(std::memory_order_relaxed), dhs, ldh);
     } else {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;
@@ -847,7 +844,6 @@ int make_upper_ctx(const Ctx& c0, const sad_rnn_layer* upper, int n_upper, int i
     if (upper == nullptr) return fail(-1, "n_upper=%d but upper is NULL", n_upper);
     sad_dims du = {c0.s.B, c0.s.T, 1, 2 * c0.s.H, c0.s.H, c0.s.L, c0.s.cell};
     if (make_ctx(&du, upper[i].packed, upper[i].workspace, (void*)c0.st, cu)) return -1;
-    cu->per_step = true;
     return 0;
 }
 
@@ -881,8 +877,7 @@ int run_upper_fwd(const Ctx& c0, const sad_fwd_args* a) {
 
 int forward_impl(const Ctx& c_in, const sad_fwd_args* a) {
     if (check_ptr(a, "args")) return -1;
-    Ctx c = c_in;
-    c.per_step = a->n_upper != 0;
+    const Ctx& c = c_in;
     const Shape& s = c.s;
     if (check_ptr(a->src, "src") || check_ptr(a->lengths, "lengths") || check_ptr(a->mask, "mask") ||
         check_ptr(a->logits, "logits") || check_ptr(a->weights, "weights"))
@@ -958,7 +953,6 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
     } else {
         // top-down through the layers above the first: d(final hidden) enters the last layer only; every
         // layer's d(input) is the per-step output gradient of the layer below it
-        c.per_step = true;
         Ctx cu[SAD_MAX_UPPER_LAYERS];
         for (int i = 0; i < a->n_upper; ++i)
             if ((rc = make_upper_ctx(c, a->upper, a->n_upper, i, &cu[i])) != 0) return rc;
@@ -972,6 +966,7 @@ int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, v
                 return fail(-2, "hipMemsetAsync(DZ) failed");
             if (i != top && hipMemsetAsync(at<unsigned char>(u.ws, u.wl.off[SAD_WS_DHFIN]), 0, u.wl.bytes[SAD_WS_DHFIN], u.st) != hipSuccess)
                 return fail(-2, "hipMemsetAsync(DHFIN) failed");
+            if ((rc = run_zero_sync(u, false)) != 0) return rc;      // hand-off counters of this layer's BPTT
             if ((rc = run_lstm_bwd(u, dhs, u.s.Ep)) != 0) return rc;
             if ((rc = run_inproj_bwd(u)) != 0) return rc;
             if (a->upper[i].drop_keep != nullptr &&

@@ -103,6 +103,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own copy of the HIP runtime, and libsad must bind to that one — loaded the other
+    # way round the process holds two runtimes and libsad's first launch fails with "no ROCm-capable device"
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libsad.so not found at %s — the HIP extension is required (no CPU/eager fallback). "

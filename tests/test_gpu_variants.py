@@ -33,6 +33,22 @@ def _module(which, hdr, params, dropout=0.0):
     return m.to("cuda:0")
 
 
+@pytest.fixture
+def per_step_kernels():
+    """Run the recurrences as one launch per time step (the persistent kernels are the default for one-layer
+    configurations)."""
+    import torch  # noqa: F401  (first: libsad must bind to the HIP runtime torch loads, not to a second copy)
+    from sad_amd import lib
+    lib.debug_set(lib.DBG_NO_PERSIST, 1)
+    yield
+    lib.debug_set(lib.DBG_NO_PERSIST, 0)
+
+
+@pytest.mark.parametrize("tag", ["gru_bi", "gru_uni", "lstm_uni"])
+def test_variant_golden_per_step_kernels(tag, per_step_kernels):
+    test_variant_golden(tag)
+
+
 @pytest.mark.parametrize("tag", VARIANT_TAGS)
 def test_variant_golden(tag):
     import torch

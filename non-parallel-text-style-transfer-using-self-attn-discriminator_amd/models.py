@@ -24,8 +24,9 @@ embedded into it here, with autograd carrying the gradients back to the real par
   outputs of the layer below; nn.LSTM's inter-layer dropout (classifier copy, training mode) uses masks drawn
   here.
 
-The shipped configuration (LSTM, bidirectional, one layer) passes its parameters through untouched and is
-the only one that runs the persistent recurrence kernels.
+The shipped configuration (LSTM, bidirectional, one layer) passes its parameters through untouched.  Every
+configuration runs the same kernels, the persistent recurrences included (GRU: a second cell epilogue; layers
+above the first: their own launch per layer).
 
 The submodules (``nn.Embedding``, ``nn.LSTM`` / ``nn.GRU``, ``nn.Linear``) exist only as PARAMETER HOLDERS so
 that ``named_parameters()`` filtering, ``requires_grad`` freezing, ``clip_grad_norm_`` and the

@@ -1,6 +1,5 @@
 """SURVEY.md §8 f4 variants at the cfg3 shape (frozen discriminator, dense bf16 soft tokens, fwd + bwd to dS):
-ms per step of the drop-in module for every cell / direction / depth the reference constructor accepts.
-Only the shipped configuration runs the persistent recurrences; the others run one launch per time step."""
+ms per step of the drop-in module for every cell / direction / depth the reference constructor accepts."""
 import json, os, sys
 from types import SimpleNamespace
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1854,6 +1854,16 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws(Shape s, const bf16raw* 
 // MFMA time; with the roles split the tile time is the maximum of the three.
 // LDS: 2 W_emb tile buffers (2 x 40 KB at E = 300) + 2 output tile buffers (2 x 32 KB), one
 // workgroup barrier per tile.
+// 64-byte-aligned stores (round 2): the rows of dS start at arbitrary 2-byte offsets (V = 9353: pitch 18706 B), so a
+// tile's 128-byte row segment used to straddle 64-byte blocks that the neighbouring tile completed an iteration
+// later, and the two partial writes reached HBM separately (WRITE_SIZE 1.3 x the tensor; 276 us at V = 9353
+// against 187 us at V = 9344).  Now the compute waves write their results into the LDS tile shifted by the
+// row's misalignment (a register funnel between lanes 16 apart, so LDS writes stay aligned 16-byte chunks), the
+// wrapped tail of a tile waits in registers for the next tile's buffer, and the store waves issue plain aligned
+// stores of two whole 64-byte blocks per row: 280 -> 237 us back to back, 222 -> 210 us inside the step.
+// Tried on the way (all measured, all slower): re-aligning in the store waves (two LDS reads + funnel per chunk:
+// 342 us), element-wise shifted LDS writes from the compute waves (48 ds_write_b16 per lane: 302 us in the step),
+// every wave storing a share of the tile (321 us), four compute waves of 64 rows (no change).
 // ------------------------------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw* __restrict__ DX,
@@ -1878,42 +1888,62 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
 
     if (wave >= 10) {
         // -------------------------------------- store waves --------------------------------------
-        // (Measured, round 2: with V = 9353 a row starts at an arbitrary 2-byte offset, the 128-byte row segment
-        // of a tile straddles 64-byte blocks that the next tile completes an iteration later, and the two partial
-        // writes reach HBM separately: WRITE_SIZE = 1.5 x the tensor, 276 us against 187 us for V = 9344.
-        // Re-aligning the segments here — funnel of two LDS chunks per lane plus a carry strip — cost more in LDS
-        // reads (the kernel runs at the LDS read rate of its compute waves) than the aligned stores gave back:
-        // 342 us.  Callers that own the allocation pad the row pitch instead: producer.SoftTokenAssembler.)
+        // The LDS tile of iteration j holds, for row r, the columns [64 j - phi_r, 64 j + 64 - phi_r) of the row,
+        // phi_r = the row's offset from a 64-byte boundary in elements (the compute waves write their results
+        // shifted, see below): lane (r, c) stores chunk c to an address that is 16-byte aligned, and the 8 lanes of
+        // a row cover two whole 64-byte blocks.  Columns outside [64 nt0, min(64 nt1, V)) are clipped: the head of
+        // the first tile has no data, the flush tile (iteration ntl + 1) only holds the last phi_r columns.
         const int ls = tid - 640;
-        long long obase[16];
-        bool rok[16];
+        bf16raw* prow[16];                                     // row start minus the row's misalignment (64-byte aligned), or null
+        int phs[16];                                           // that misalignment, elements
+        const int c = ls & 7;
+        const unsigned dS_lo = (unsigned)((uintptr_t)dS >> 1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + (ls >> 3) + 16 * i;
-            rok[i] = m < M;
-            const int t = rok[i] ? m / s.B : 0, b = rok[i] ? m - t * s.B : 0;
-            obase[i] = (long long)t * sT + (long long)b * sB;
+            const int t = m / s.B, b = m - t * s.B;
+            const long long ob = (long long)t * sT + (long long)b * sB;
+            phs[i] = (int)((dS_lo + (unsigned)ob) & 31u);
+            prow[i] = m < M ? dS + ob - phs[i] + c * 8 : nullptr;
         }
-        const int c = ls & 7;
+        const int col_lo = nt0 * BN, col_hi = nt1 * BN < V ? nt1 * BN : V;
         K1P_DECL
         __syncthreads();                                       // prologue barrier
-        for (int it = 0; it <= ntl; ++it) {
+        for (int it = 0; it <= ntl + 1; ++it) {
             K1P_T(0)
             K1P_T(1)
             if (it >= 1) {
                 const unsigned char* buf = Os + ((it - 1) & 1) * OUTB;
-                const int n = (nt0 + it - 1) * BN + c * 8;
+                // all 16 LDS reads first: behind the per-row branches below they are not hoisted, and sixteen
+                // read -> wait -> store rounds cost 2.7 us per tile
+                u32x4 vv[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int r = (ls >> 3) + 16 * i;
-                    const u32x4 v = *(const u32x4*)&buf[r * 128 + ((c ^ (r & 7)) << 4)];
-                    if (!rok[i] || n >= V) continue;
-                    bf16raw* p = dS + obase[i] + n;
-                    if (n + 8 <= V) {
-                        *(u32x4h*)p = v;
-                    } else {
-                        for (int e = 0; e < 8; ++e)
-                            if (n + e < V) p[e] = (bf16raw)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    vv[i] = *(const u32x4*)&buf[r * 128 + ((c ^ (r & 7)) << 4)];
+                }
+                const int seg = (nt0 + it - 1) * BN;             // first stream position of this tile
+                if (seg - 31 >= col_lo && seg + BN <= col_hi) {
+                    // interior tile (workgroup-uniform): every chunk lies inside the column range
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (prow[i] != nullptr) *(u32x4*)(prow[i] + seg) = vv[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (prow[i] == nullptr) continue;
+                        bf16raw* p = prow[i] + seg;            // columns col0 .. col0 + 7 of the row
+                        const int col0 = seg + c * 8 - phs[i];
+                        const int lo = col0 > col_lo ? col0 : col_lo, hi = col0 + 8 < col_hi ? col0 + 8 : col_hi;
+                        if (hi <= lo) continue;
+                        const u32x4 v = vv[i];
+                        if (hi - lo == 8) {
+                            *(u32x4*)p = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (col0 + e >= lo && col0 + e < hi) p[e] = (bf16raw)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                        }
                     }
                 }
             }
@@ -1954,7 +1984,7 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
         load_tile(1);
         __syncthreads();                                       // prologue barrier: tile 0 ready
         K1P_DECL
-        for (int it = 0; it <= ntl; ++it) {
+        for (int it = 0; it <= ntl + 1; ++it) {
             K1P_T(0)
             if (it + 1 < ntl) {
                 to_lds(it + 1);
@@ -1989,19 +2019,75 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
             if (wave_any && mrow[tm] < M) v = *(const u32x4*)(DX + (long long)mrow[tm] * EP + ks * 32 + (lane >> 4) * 8);
             a[tm][ks] = __builtin_bit_cast(bf16x8, v);
         }
-    int roff[4], rsw[4];
+    // B-fragment addresses: W row rho = 16 tn + (lane & 15), chunk (4 ks + (lane >> 4)) ^ ((rho >> 1) & 7).  The
+    // swizzle term does not depend on tn, its low two bits only touch the lane's quarter index and its bit 2 swaps
+    // k-steps 2j and 2j + 1: two base registers and immediate offsets instead of eight address registers.
+    const int rswz = ((lane & 15) >> 1) & 7, sflip = (rswz >> 2) & 1;
+    const int b_even = (lane & 15) * ROWB + (((lane >> 4) ^ (rswz & 3)) << 4) + sflip * 64;   // + 64 ks          (ks even)
+    const int b_odd = b_even + 64 - sflip * 128;                                              // + 64 (ks - 1)    (ks odd)
+    // Shifted output: element (row r, tile column x) goes to LDS position y = x + phi_r of the row's stream.  The
+    // shift is done in registers so that every LDS write stays an aligned 16-byte chunk: output chunk O_i =
+    // last f elements of raw chunk i-1 ++ first 8-f of raw chunk i (f = phi_r & 7; raw chunk -1 = chunk 7 of the
+    // previous tile), written at chunk position i + (phi_r >> 3).  The left neighbour of a lane's chunk lives 16
+    // lanes below (lanes 16 apart hold neighbouring 8-column groups of one row): one ds_bpermute per dword.
+    // Positions 8 and above belong to the head of the NEXT tile's buffer, which the store waves are reading during
+    // this iteration: those chunks (upper half of the tile only, phi_r < 32) wait in registers until the top of
+    // the next iteration.
+    const int q4 = lane >> 4;
+    int phi[2];                                                // misalignment of this lane's two rows, elements (0..31)
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-        const int rho = tn * 16 + (lane & 15);
-        roff[tn] = rho * ROWB;
-        rsw[tn] = (rho >> 1) & 7;
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = mrow[tm] < M ? mrow[tm] : 0;
+        const int t = m / s.B, b = m - t * s.B;
+        phi[tm] = (int)(((unsigned)((uintptr_t)dS >> 1) + (unsigned)((long long)t * sT + (long long)b * sB)) & 31u);
     }
+    // window of 16 bytes at byte offset 16 - 2 f in (left, cur): barrel shift by dwords with bit-selects, then by
+    // 0 or 16 bits (the masks are recomputed per use: kept across the tile loop they cost registers that spill)
+    auto funnel = [&](const u32x4& L, const u32x4& C, int f) {
+        const int sb = 16 - 2 * f, d = (sb >> 2) & 3;
+        const unsigned m1 = (d & 1) ? 0xffffffffu : 0u, m2 = (d & 2) ? 0xffffffffu : 0u, sh16 = (unsigned)(sb & 2) * 8u;
+        const unsigned x[8] = {L[0], L[1], L[2], L[3], C[0], C[1], C[2], C[3]};
+        unsigned y[7], z[5];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) y[i] = (x[i + 1] & m1) | (x[i] & ~m1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) z[i] = (y[i + 2] & m2) | (y[i] & ~m2);
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = f == 0 ? C[w] : __builtin_amdgcn_alignbit(z[w + 1], z[w], sh16);
+        return o;
+    };
+    auto from_below = [&](const u32x4& v) {                    // the value of the lane 16 below (lane 0..15: of lane + 48)
+        u32x4 o;
+        const int src = ((lane - 16) & 63) << 2;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)v[w]);
+        return o;
+    };
+    u32x4 prev_hi[2], held[2];                                 // raw upper chunk of the previous tile; shifted chunk waiting to wrap
+    prev_hi[0] = prev_hi[1] = held[0] = held[1] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();                                           // prologue barrier
     K1P_DECL
-    for (int it = 0; it <= ntl; ++it) {
+    for (int it = 0; it <= ntl + 1; ++it) {
         K1P_T(0)
+        asm volatile("" : "+v"(phi[0]), "+v"(phi[1]));         // nothing derived from phi is hoisted out of the loop
+        int fsh[2], qsh[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            fsh[tm] = phi[tm] & 7;
+            qsh[tm] = phi[tm] >> 3;
+        }
+        if (it >= 1 && it <= ntl) {                            // wrapped chunks of tile it - 1 -> head of buffer it & 1
+            unsigned char* ob = Os + (it & 1) * OUTB;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int r = wave * 32 + tm * 16 + (lane & 15);
+                const int g = 4 + q4 + qsh[tm];
+                if (g >= 8) *(u32x4*)&ob[r * 128 + (((g - 8) ^ (r & 7)) << 4)] = held[tm];
+            }
+        }
         K1P_T(1)
-        if (it < ntl) {
+        if (it <= ntl) {
             const unsigned char* buf = Bs + (it & 1) * TILEB;
             unsigned char* ob = Os + (it & 1) * OUTB;
             f32x4 acc[2][4];
@@ -2009,13 +2095,13 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (wave_any) {
+            if (wave_any && it < ntl) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     bf16x8 bfr[4];
 #pragma unroll
                     for (int tn = 0; tn < 4; ++tn)
-                        bfr[tn] = *(const bf16x8*)&buf[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+                        bfr[tn] = *(const bf16x8*)&buf[((ks & 1) ? b_odd + 64 * (ks - 1) : b_even + 64 * ks) + tn * 16 * ROWB];
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -2023,14 +2109,22 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
                 }
             }
+            // (iteration ntl is the flush: zero "raw" chunks push the last f elements of the last tile out)
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 const int r = wave * 32 + tm * 16 + (lane & 15);
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int c = 4 * pr + (lane >> 4);        // columns 32 pr + 8 (lane >> 4) .. + 7
-                    *(u32x4*)&ob[r * 128 + ((c ^ (r & 7)) << 4)] = pack_bf16x8(acc[tm][2 * pr], acc[tm][2 * pr + 1]);
-                }
+                const u32x4 lo = pack_bf16x8(acc[tm][0], acc[tm][1]);      // raw chunk q4     (columns  8 q4 .. + 7)
+                const u32x4 hi = pack_bf16x8(acc[tm][2], acc[tm][3]);      // raw chunk 4 + q4 (columns 32 + 8 q4 .. + 7)
+                // left neighbours: lanes 16 below hold chunks q4 - 1 / 3 + q4; for q4 == 0 the lane 48 above holds
+                // chunk 3 (its lower chunk) and, from the previous tile, chunk 7 (its upper chunk)
+                const u32x4 left_lo = from_below(q4 == 3 ? prev_hi[tm] : lo);
+                const u32x4 left_hi = from_below(q4 == 3 ? lo : hi);
+                prev_hi[tm] = hi;
+                const u32x4 o_lo = funnel(left_lo, lo, fsh[tm]), o_hi = funnel(left_hi, hi, fsh[tm]);
+                const int g_lo = q4 + qsh[tm], g_hi = 4 + q4 + qsh[tm];    // g_lo <= 6
+                *(u32x4*)&ob[r * 128 + ((g_lo ^ (r & 7)) << 4)] = o_lo;
+                if (g_hi < 8) *(u32x4*)&ob[r * 128 + ((g_hi ^ (r & 7)) << 4)] = o_hi;
+                held[tm] = o_hi;
             }
         }
         K1P_T(2)

@@ -6,7 +6,7 @@ import torch
 from sad_amd import functional as Fn, lib as L
 dev = torch.device("cuda:0")
 T, B, E = 32, 896, 300
-for V in (9353, 9344, 9408, 9352):
+for V in (9353, 9344, 9376, 9360, 9352):
     W = torch.randn(V, E, device=dev) * 0.05
     pw = Fn._se_packed(W)
     d, ws = Fn._se_workspace(B, T, V, E, dev)

@@ -2095,36 +2095,62 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (wave_any && it < ntl) {
+            // The tile is multiplied in two 32-column halves; the pack / funnel / LDS write of the lower half sits
+            // between them in one basic block, so that it overlaps the MFMAs of the upper half (both compute waves
+            // of a SIMD meet the tile barrier in phase: without this the MFMA pipe idles through the epilogue).
+            auto half = [&](int pr) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 bfr[4];
+                    bf16x8 bfr[2];
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        bfr[tn] = *(const bf16x8*)&buf[((ks & 1) ? b_odd + 64 * (ks - 1) : b_even + 64 * ks) + tn * 16 * ROWB];
+                    for (int h = 0; h < 2; ++h)
+                        bfr[h] = *(const bf16x8*)&buf[((ks & 1) ? b_odd + 64 * (ks - 1) : b_even + 64 * ks) + (2 * pr + h) * 16 * ROWB];
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                        for (int tn = 0; tn < 4; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], a[tm][ks], acc[tm][tn], 0, 0, 0);
+                        for (int h = 0; h < 2; ++h)
+                            acc[tm][2 * pr + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[h], a[tm][ks], acc[tm][2 * pr + h], 0, 0, 0);
                 }
-            }
-            // (iteration ntl is the flush: zero "raw" chunks push the last f elements of the last tile out)
+            };
+            u32x4 lo[2];
+            // raw chunk q4 (columns 8 q4 .. + 7): left neighbour = chunk q4 - 1 of the lane 16 below; for q4 == 0 the
+            // lane 48 above holds chunk 7 of the PREVIOUS tile (its upper chunk)
+            auto epi_lo = [&]() {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int r = wave * 32 + tm * 16 + (lane & 15);
-                const u32x4 lo = pack_bf16x8(acc[tm][0], acc[tm][1]);      // raw chunk q4     (columns  8 q4 .. + 7)
-                const u32x4 hi = pack_bf16x8(acc[tm][2], acc[tm][3]);      // raw chunk 4 + q4 (columns 32 + 8 q4 .. + 7)
-                // left neighbours: lanes 16 below hold chunks q4 - 1 / 3 + q4; for q4 == 0 the lane 48 above holds
-                // chunk 3 (its lower chunk) and, from the previous tile, chunk 7 (its upper chunk)
-                const u32x4 left_lo = from_below(q4 == 3 ? prev_hi[tm] : lo);
-                const u32x4 left_hi = from_below(q4 == 3 ? lo : hi);
-                prev_hi[tm] = hi;
-                const u32x4 o_lo = funnel(left_lo, lo, fsh[tm]), o_hi = funnel(left_hi, hi, fsh[tm]);
-                const int g_lo = q4 + qsh[tm], g_hi = 4 + q4 + qsh[tm];    // g_lo <= 6
-                *(u32x4*)&ob[r * 128 + ((g_lo ^ (r & 7)) << 4)] = o_lo;
-                if (g_hi < 8) *(u32x4*)&ob[r * 128 + ((g_hi ^ (r & 7)) << 4)] = o_hi;
-                held[tm] = o_hi;
+                for (int tm = 0; tm < 2; ++tm) {
+                    const int r = wave * 32 + tm * 16 + (lane & 15);
+                    lo[tm] = pack_bf16x8(acc[tm][0], acc[tm][1]);
+                    const u32x4 left_lo = from_below(q4 == 3 ? prev_hi[tm] : lo[tm]);
+                    const u32x4 o_lo = funnel(left_lo, lo[tm], fsh[tm]);
+                    const int g_lo = q4 + qsh[tm];                                 // <= 6
+                    *(u32x4*)&ob[r * 128 + ((g_lo ^ (r & 7)) << 4)] = o_lo;
+                }
+            };
+            // raw chunk 4 + q4 (columns 32 + 8 q4 .. + 7): left neighbour = chunk 3 + q4 (q4 == 0: the lower chunk
+            // of the lane 48 above)
+            auto epi_hi = [&]() {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const int r = wave * 32 + tm * 16 + (lane & 15);
+                    const u32x4 hi = pack_bf16x8(acc[tm][2], acc[tm][3]);
+                    const u32x4 left_hi = from_below(q4 == 3 ? lo[tm] : hi);
+                    prev_hi[tm] = hi;
+                    const u32x4 o_hi = funnel(left_hi, hi, fsh[tm]);
+                    const int g_hi = 4 + q4 + qsh[tm];
+                    if (g_hi < 8) *(u32x4*)&ob[r * 128 + ((g_hi ^ (r & 7)) << 4)] = o_hi;
+                    held[tm] = o_hi;
+                }
+            };
+            if (wave_any && it < ntl) {
+                half(0);
+                epi_lo();
+                half(1);
+                epi_hi();
+            } else {
+                // rows none of whose tokens is needed, and the flush iteration ntl (zero "raw" chunks push the last f
+                // elements of the last tile out)
+                epi_lo();
+                epi_hi();
             }
         }
         K1P_T(2)

@@ -336,3 +336,73 @@ def test_stage_entry_points_and_joint_upstream_gradients():
     torch.cuda.synchronize()
     ws.check()
     assert torch.equal(ws.view("DZ", torch.bfloat16), dz0)
+
+
+@pytest.mark.parametrize("V", [9, 33, 64, 95, 130, 1000, 4097])
+def test_soft_token_gradient_alignment_edges(V):
+    """K1' (d soft tokens, bf16, E = 300 -> the A-stationary kernel with 64-byte-aligned stores): vocabulary sizes
+    below / across / far above one 64-column tile, row pitches of every alignment class, a storage offset that
+    moves the base address off the 64-byte grid, time-major and batch-major layouts.  Every element of dS must
+    match the reference contraction dX . W^T (bf16 inputs, fp32 accumulation, bf16 result), and the elements
+    around the tensor must stay untouched (the aligned stores clip at the row ends)."""
+    import torch
+    from sad_amd import functional as Fn
+    dev = torch.device("cuda:0")
+    E = 300
+    g = torch.Generator(device=dev)
+    g.manual_seed(V)
+    W = (torch.randn((V, E), generator=g, device=dev) * 0.1)
+    for (T, B, batch_major, off) in ((5, 37, False, 0), (3, 300, False, 3), (7, 19, True, 5)):
+        guard = 64
+        flat = torch.full((guard + off + T * B * V + guard,), 7.0, dtype=torch.bfloat16, device=dev)
+        body = flat[guard + off: guard + off + T * B * V]
+        if batch_major:
+            S = body.view(B, T, V)
+        else:
+            S = body.view(T, B, V).transpose(0, 1)           # [B,T,V] view of time-major storage
+        S.copy_(torch.softmax(torch.randn((B, T, V), generator=g, device=dev), -1).to(torch.bfloat16))
+        S = S.detach().requires_grad_(True)
+        G = torch.randn((B, T, E), generator=g, device=dev).to(torch.bfloat16)
+        Fn.soft_embedding(S, W).backward(G)
+        want = (G.float() @ W.to(torch.bfloat16).float().t())
+        got = S.grad.float()
+        assert got.shape == want.shape
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 1e-2 * scale + 1e-6, (V, T, B, batch_major, off)
+        # the gradient keeps the layout of S, so it is a view-shaped tensor of its own: nothing outside may be written;
+        # check the guard bands of the INPUT storage too (soft tokens are read-only for the kernels)
+        assert bool((flat[:guard + off] == 7.0).all()) and bool((flat[-guard:] == 7.0).all())
+
+
+@pytest.mark.parametrize("V", [9, 64, 95, 4097])
+def test_soft_token_gradient_writes_stay_inside_rows(V):
+    """Same kernel through the stage entry sad_softemb_bwd with the OUTPUT inside a guarded buffer: the aligned
+    stores start up to 31 elements in front of a row's first column and must clip there, at V, and at the column
+    ranges of the workgroups — nothing around the tensor may change, every element inside must."""
+    import ctypes
+    import torch
+    from sad_amd import functional as Fn, lib as L
+    dev = torch.device("cuda:0")
+    T, B, E = 6, 70, 300
+    g = torch.Generator(device=dev)
+    g.manual_seed(100 + V)
+    W = torch.randn((V, E), generator=g, device=dev) * 0.1
+    pw = Fn._se_packed(W)
+    d, ws = Fn._se_workspace(B, T, V, E, dev)
+    Ep = L.padded_dims(d)["Ep"]
+    dx = ws.view("DX", torch.bfloat16)[:T * B * Ep].view(T * B, Ep)
+    dx.zero_()
+    dx[:, :E] = torch.randn((T * B, E), generator=g, device=dev).to(torch.bfloat16)
+    want = dx[:, :E].float() @ W.to(torch.bfloat16).float().t()
+    for off in (0, 1, 13, 32):
+        guard = 96
+        flat = torch.full((guard + off + T * B * V + guard,), 3.0, dtype=torch.bfloat16, device=dev)
+        dS = flat[guard + off: guard + off + T * B * V].view(T, B, V)
+        L.check(L.load().sad_softemb_bwd(ctypes.byref(d), Fn._ptr(pw.buf), Fn._ptr(dS), L.SRC_BF16, dS.stride(1), dS.stride(0),
+                                         Fn._ptr(ws.buf), Fn._stream_ptr()), "sad_softemb_bwd")
+        torch.cuda.synchronize()
+        assert bool((flat[:guard + off] == 3.0).all()), (V, off, "wrote in front of the tensor")
+        assert bool((flat[guard + off + T * B * V:] == 3.0).all()), (V, off, "wrote behind the tensor")
+        got = dS.reshape(T * B, V).float()
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 1e-2 * scale + 1e-6, (V, off)

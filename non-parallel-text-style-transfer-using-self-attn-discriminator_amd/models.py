@@ -108,7 +108,6 @@ class _SelfAttnBase(nn.Module):
         layout, built from the real parameters with differentiable torch ops (cat with zeros): the shipped
         configuration returns its parameters themselves."""
         sd = dict(self.named_parameters())
-        H = self.hidden_size
 
         def widen(w):            # uni-directional: [., H] -> [., 2H] (the reverse half is exactly zero)
             return w if self.bidirectional else torch.cat([w, torch.zeros_like(w)], 1)

@@ -168,7 +168,7 @@ def kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits, weights):
     a.logits, a.weights = logits.data_ptr(), weights.data_ptr()
     D = ctypes.byref(d)
     calls = [
-        ("K1 soft-embedding fwd (k_tile_list + k_softemb_fwd_sk + k_softemb_fwd_fix)", "mfma+hbm",
+        ("K1 soft-embedding fwd (k_softemb_fwd_sk + k_softemb_fwd_fix)", "mfma+hbm",
          lambda: L.sad_softemb_fwd(D, p(pw.buf), p(S), kind, V, B * V, p(ws.buf), st()),
          2.0 * rows * V * E, rows * V * esz + M * Ep * 2),
         ("K2a+K3 in-projection fwd (k_inproj_fwd_rs3)", "mfma",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 210 /* 0.2.1 */
+#define SAD_VERSION 211 /* 0.2.1 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -188,7 +188,7 @@ enum sad_ws_field {
     SAD_WS_DL,       /* fp32 [B][L]  dlogits as used by the backward */
     SAD_WS_DWA,      /* fp32 [B][Hp] per-sentence d linear_attn.weight */
     SAD_WS_DSSUM,    /* fp32 [B]     per-sentence d linear_attn.bias */
-    SAD_WS_ROWS,     /* int32 [3][T*B] compacted lists of contributing token rows (weight gradients) */
+    SAD_WS_ROWS,     /* int32 [3][T*B] compacted lists of contributing token rows (in-projection, weight gradients) */
     SAD_WS_NROWS,    /* int32 [4]    their lengths */
     SAD_WS_SYNC,     /* u32: hand-off counters of the persistent recurrence (one 128-B line per sentence
                         tile and direction), then one line with the timeout words: [0] forward recurrence,
@@ -257,10 +257,13 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
                                void* stream);
 
 /* Single stages, for unit tests and for timing the dominant kernels in isolation (bench.py).
- * sad_prep: length clamp + mask guard + need bits (reference transfer/models.py:865-867).
+ * sad_prep: length clamp + mask guard + need bits (reference transfer/models.py:865-867), and from the
+ *           need bits the compacted row lists (ROWS / NROWS), the list of non-empty 128-row tiles
+ *           (K1TILES) and zeroed hand-off words (SYNC): the same launch(es) that open sad_forward.
  * sad_softemb_fwd:  X = S @ W_emb            (reference transfer/models.py:898), S -> workspace X.
  * sad_softemb_bwd:  dS = dX @ W_emb^T        (its autograd), workspace DX -> dsrc.
- * Both read the need bits a previous sad_prep / sad_forward left in `workspace`. */
+ * Both (and sad_param_grads_accumulate) read what a previous sad_prep / sad_forward left in `workspace`:
+ * need bits, row lists, tile list. */
 int sad_prep(const sad_dims* d, const int32_t* lengths, uint8_t* mask, int64_t mask_stride_b,
              int64_t mask_stride_t, int32_t guard, void* workspace, void* stream);
 int sad_softemb_fwd(const sad_dims* d, const void* packed, const void* src, int32_t src_kind,

@@ -19,7 +19,7 @@
 // No other load in the kernel touches bytes another workgroup writes during the launch (G tiles and
 // Cs are private to the workgroup; W_hh and lens are read-only).
 // Counters are zeroed in front of every launch by a kernel of the same call that runs earlier on the
-// stream (k_prep in the forward, k_attn_bwd in the backward: a separate memset node cost 4.5 us).  All workgroups must be
+// stream (k_prep_lists / k_prep in the forward, k_attn_bwd in the backward: a separate memset node cost 4.5 us).  All workgroups must be
 // co-resident: the host checks the grid against the occupancy query and otherwise runs the
 // one-launch-per-step kernels.  Spins are bounded: a timeout raises the error word (checked by
 // k_attn_fwd, which then writes NaN logits / loss for the whole batch, and by the host helpers) and

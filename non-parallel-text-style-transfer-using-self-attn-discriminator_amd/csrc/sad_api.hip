@@ -271,7 +271,6 @@ int run_softemb_fwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
         float* slabs = at<float>(ws, wl.off[SAD_WS_K1SLABS]);
         const int cus = device_cus();
         const int nwg = cus > K1_MAX_WGS ? K1_MAX_WGS : cus;
-        hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
         if (kind == SAD_SRC_F32) {
             allow_lds((const void*)k_softemb_fwd_sk<SRC_F32>, lds3, 1024);
             hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_F32>, dim3(nwg), dim3(1024), lds3, st, s, src, sT, sB, need, tiles, wembT, X, slabs);
@@ -336,9 +335,26 @@ int run_softemb_bwd(const Shape& s, const PackedLayout& pl, const WsLayout& wl, 
 
 int run_prep(const Shape& s, const WsLayout& wl, void* ws, const int32_t* lengths, uint8_t* mask, long long msb,
              long long mst, int guard, hipStream_t st) {
-    hipLaunchKernelGGL(k_prep, dim3(ceil_div(s.B, 64)), dim3(64), 0, st, s, lengths, mask, msb, mst, guard,
-                       at<unsigned char>(ws, wl.off[SAD_WS_NEED]), at<int>(ws, wl.off[SAD_WS_LENS]),
-                       at<unsigned>(ws, wl.off[SAD_WS_SYNC]), (int)(wl.bytes[SAD_WS_SYNC] / 4));
+    unsigned char* need = at<unsigned char>(ws, wl.off[SAD_WS_NEED]);
+    int* lens = at<int>(ws, wl.off[SAD_WS_LENS]);
+    unsigned* sync = at<unsigned>(ws, wl.off[SAD_WS_SYNC]);
+    const int sync_words = (int)(wl.bytes[SAD_WS_SYNC] / 4);
+    int* rows = at<int>(ws, wl.off[SAD_WS_ROWS]);
+    int* nrows = at<int>(ws, wl.off[SAD_WS_NROWS]);
+    int* tiles = wl.bytes[SAD_WS_K1TILES] != 0 ? at<int>(ws, wl.off[SAD_WS_K1TILES]) : nullptr;
+    if (s.M <= PREPL_MAX_M && s.B <= PREPL_MAX_B) {
+        // one launch: need bits, compacted row lists, list of non-empty 128-row tiles
+        allow_lds((const void*)k_prep_lists, prepl_lds_bytes(PREPL_MAX_M, PREPL_MAX_B), 1024);
+        hipLaunchKernelGGL(k_prep_lists, dim3(ceil_div(s.M, 1024)), dim3(1024), prepl_lds_bytes(s.M, s.B), st, s, lengths, mask,
+                           msb, mst, guard, need, lens, sync, sync_words, rows, nrows, tiles);
+        SAD_CHECK_LAUNCH("k_prep_lists");
+        return 0;
+    }
+    hipLaunchKernelGGL(k_prep, dim3(ceil_div(s.B, 64)), dim3(64), 0, st, s, lengths, mask, msb, mst, guard, need, lens, sync,
+                       sync_words);
+    // compacted lists of the needed token rows (in-projection, weight gradients) and of the non-empty row tiles (K1)
+    hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(s.M, 1024)), dim3(256), 0, st, s, need, rows, nrows);
+    if (tiles != nullptr) hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, st, s.M, need, tiles);
     SAD_CHECK_LAUNCH("k_prep");
     return 0;
 }
@@ -764,7 +780,6 @@ int run_inproj_bwd(const Ctx& c) {
             float* slabs = at<float>(c.ws, c.wl.off[SAD_WS_K1SLABS]);
             const int cus = device_cus();
             const int nwg = cus > K1_MAX_WGS ? K1_MAX_WGS : cus;
-            hipLaunchKernelGGL(k_tile_list, dim3(1), dim3(1024), 0, c.st, s.M, need, tiles);
             allow_lds((const void*)k_softemb_fwd_sk<SRC_BF16>, lds3, 1024);
             hipLaunchKernelGGL(k_softemb_fwd_sk<SRC_BF16>, dim3(nwg), dim3(1024), lds3, c.st, sp, (const void*)DZ,
                                (long long)s.B * s.Ncat, (long long)s.Ncat, need, tiles, wT, DX, slabs);
@@ -858,9 +873,6 @@ int run_upper_fwd(const Ctx& c0, const sad_fwd_args* a) {
         // lengths / need bits / row lists / zeroed counters of this layer's workspace (the mask was already
         // mutated by layer 0's k_prep; the guard is idempotent)
         if ((rc = run_prep(c.s, c.wl, c.ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, c.st)) != 0) return rc;
-        hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(c.s.M, 1024)), dim3(256), 0, c.st, c.s,
-                           at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]), at<int>(c.ws, c.wl.off[SAD_WS_ROWS]),
-                           at<int>(c.ws, c.wl.off[SAD_WS_NROWS]));
         const long long total = (long long)c.s.M * c.s.Ep;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 8192) blocks = 8192;
@@ -884,13 +896,9 @@ int forward_impl(const Ctx& c_in, const sad_fwd_args* a) {
         return -1;
     if (a->loss != nullptr && a->labels == nullptr) return fail(-1, "loss requested without labels");
     bf16raw* X = at<bf16raw>(c.ws, c.wl.off[SAD_WS_X]);
-    // (k_prep also zeroes the hand-off counters and timeout words of the recurrence)
+    // need bits, row lists, tile list (the same launch zeroes the hand-off counters and timeout words of the recurrence)
     int rc = run_prep(s, c.wl, c.ws, a->lengths, a->mask, a->mask_stride_b, a->mask_stride_t, a->guard, c.st);
     if (rc) return rc;
-    // compacted lists of the needed token rows (in-projection here, weight gradients later)
-    hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(s.M, 1024)), dim3(256), 0, c.st, s, at<unsigned char>(c.ws, c.wl.off[SAD_WS_NEED]),
-                       at<int>(c.ws, c.wl.off[SAD_WS_ROWS]), at<int>(c.ws, c.wl.off[SAD_WS_NROWS]));
-    SAD_CHECK_LAUNCH("k_row_lists");
     // K1 / gather
     if (a->src_kind == SAD_SRC_IDS) {
         if (check_aligned(a->src, 8, "src")) return -1;
@@ -1138,11 +1146,10 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
     const float* DWA = at<float>(ws, wl.off[SAD_WS_DWA]);
     const float* DSSUM = at<float>(ws, wl.off[SAD_WS_DSSUM]);
 
-    // Compacted lists of the contributing token rows (padding rows are never touched).
-    int* rows = at<int>(ws, wl.off[SAD_WS_ROWS]);
-    int* nrows = at<int>(ws, wl.off[SAD_WS_NROWS]);
-    hipLaunchKernelGGL(k_row_lists, dim3(ceil_div(s.M, 1024)), dim3(256), 0, st, s, need, rows, nrows);
-    SAD_CHECK_LAUNCH("k_row_lists");
+    // Compacted lists of the contributing token rows (padding rows are never touched): left in the
+    // workspace by the sad_prep / sad_forward that wrote the need bits.
+    const int* rows = at<int>(ws, wl.off[SAD_WS_ROWS]);
+    const int* nrows = at<int>(ws, wl.off[SAD_WS_NROWS]);
     // Row splits: ~2 workgroups per CU (every split costs one atomic add per output element).  The
     // list lengths live on the device, so the split is sized for the worst case (every row active).
     auto row_split = [](int rows_max, int tiles) {

@@ -344,6 +344,194 @@ __global__ __launch_bounds__(256) void k_row_lists(Shape s, const unsigned char*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_prep + k_row_lists + k_tile_list in ONE launch (the three launches cost 7 + 13 + 4 us of a 1.27 ms
+// step, and 24 of 396 us at batch 64), for M <= PREPL_MAX_M, B <= PREPL_MAX_B.  Nothing here waits on another workgroup: every workgroup rebuilds ALL need bytes in
+// LDS from the mask and the lengths (a few 10 KB, L2-resident after the first reader), counts its own
+// output offsets from them, and writes the need bytes, the three row lists and the tile-list entries of
+// its own 1024-row segment.  Workgroup 0 also writes the clamped lengths, the list totals, applies the
+// all-masked-row guard to the caller's mask and zeroes the recurrence's hand-off words.  A workgroup that
+// reads mask[b][1] after workgroup 0 unmasked it sees the value the guard produces anyway (idempotent).
+// The work is a chain of short dependent phases, so it is written for latency: 16 mask bytes per thread
+// (one 16-byte load when the mask rows allow it), no branches per byte, wave scans on DPP row shifts (a
+// ds_bpermute butterfly costs ~2 us per block reduction here), cross-wave sums as one LDS read + a row scan.
+// LDS: [Mp] need bytes in (t, b) order | 16 bytes that swallow the stores of rows past M | [B] u8 guard flags.
+// ------------------------------------------------------------------------------------------------
+constexpr int PREPL_MAX_M = 65536, PREPL_MAX_B = 2048;
+#ifndef PREP_STAMP            // phase time stamps of tools/micro/prep_phases.hip; nothing in the library
+#define PREP_STAMP(i)
+#endif
+__host__ __device__ inline size_t prepl_lds_bytes(int M, int B) { return (((size_t)M + 15) & ~(size_t)15) + 16 + (((size_t)B + 15) & ~(size_t)15); }
+
+// inclusive prefix sums over the 16 lanes of each DPP row / over the wave (total in lane 15 of a row / lane 63)
+__device__ __forceinline__ int row_scan16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);          // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);          // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);          // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);          // row_shr:8
+    return v;
+}
+__device__ __forceinline__ int wave_scan64(int v) {
+    v = row_scan16(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);          // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);          // row_bcast:31 into rows 2, 3
+    return v;
+}
+// number of set 0x01 bits among the first n (0..16) bytes of a 16-byte chunk
+__device__ __forceinline__ int popc_low_bytes(u32x4 bits, int n) {
+    int r = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int nq = n - 4 * q;
+        nq = nq < 0 ? 0 : (nq > 4 ? 4 : nq);
+        const unsigned keep = ~((0xffffffffu << (4 * nq)) << (4 * nq));
+        r += __popc(bits[q] & keep);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_prep_lists(Shape s, const int* __restrict__ lens_in, unsigned char* mask, long long msb,
+                                                    long long mst, int guard, unsigned char* __restrict__ need,
+                                                    int* __restrict__ lens,
+                                                    unsigned* __restrict__ sync, int sync_words, int* __restrict__ rows,
+                                                    int* __restrict__ nrows, int* __restrict__ tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_lds[];
+    __shared__ int red[6][16];
+    __shared__ int wsum[4][16];
+    __shared__ unsigned char tflag[PREPL_MAX_M / 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = s.M, B = s.B, T = s.T;
+    const int Mp = (M + 15) & ~15;
+    unsigned char* nl = pl_lds;
+    unsigned char* allm = pl_lds + Mp + 16;
+    const bool first = blockIdx.x == 0;
+    PREP_STAMP(0);
+    if (first)
+        for (int i = tid; i < sync_words; i += 1024) sync[i] = 0u;
+    for (int b = tid; b < B; b += 1024) allm[b] = guard && T > 1;
+    if (tid < 32) nl[Mp - 16 + tid] = 0;                      // rows past M count as not needed
+    __syncthreads();
+    // ---- need bytes in (t, b) order, without the guard; rows that have an unmasked step lose their guard flag.
+    // A thread takes 16 steps of one sentence, consecutive lanes take consecutive sentences: the byte stores of a
+    // wave then fall into 64 consecutive bytes (sentence-major chunks put them 8 deep on 8 banks: 4.7 us vs 1.x).
+    PREP_STAMP(1);
+    const int nch = (T + 15) >> 4;
+    const bool vec = mst == 1 && (msb & 15) == 0 && ((unsigned long long)mask & 15) == 0;
+    for (int u = tid; u < nch * B; u += 1024) {
+        const int tc = u / B, b = u - tc * B, t0 = tc * 16;
+        const unsigned char* mrow = mask + (long long)b * msb;
+        u32x4 w;
+        if (vec && t0 + 16 <= T) w = *(const u32x4*)(mrow + t0);
+        else {
+            unsigned char by[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) by[i] = t0 + i < T ? mrow[(long long)(t0 + i) * mst] : (unsigned char)1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = by[4 * q] | (by[4 * q + 1] << 8) | (by[4 * q + 2] << 16) | ((unsigned)by[4 * q + 3] << 24);
+        }
+        int len = lens_in[b];
+        len = len < 0 ? 0 : (len > T ? T : len);
+        int z = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned byte = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+            const bool valid = t0 + i < T;
+            nl[valid ? (t0 + i) * B + b : Mp] = (unsigned char)((t0 + i < len ? 1 : 0) | (byte != 0u ? 0 : 2));
+            z |= byte == 0u && valid;
+        }
+        if (z) allm[b] = 0;
+    }
+    __syncthreads();
+    // ---- the guard: an all-masked row gets t = 1 unmasked (transfer/models.py:865-867), in LDS and in the caller's mask
+    PREP_STAMP(2);
+    for (int b = tid; b < B; b += 1024) {
+        if (first) {
+            const int len = lens_in[b];
+            lens[b] = len < 0 ? 0 : (len > T ? T : len);
+        }
+        if (allm[b]) {
+            nl[B + b] |= 2;
+            if (first) mask[(long long)b * msb + mst] = 0;
+        }
+    }
+    __syncthreads();
+    // ---- counts over all rows (see k_row_lists), flags of the 128-row tiles, own need bytes out
+    PREP_STAMP(3);
+    const int m0 = blockIdx.x * 1024;
+    if (tid < 64 && m0 + tid * 16 < Mp) *(u32x4*)(need + m0 + tid * 16) = *(const u32x4*)(nl + m0 + tid * 16);
+    // [0] Cany(m0) [1] C1(m0) [2] C1(min(B, M)) [3] C1(min(M, m0 + B)) [4] Cany(M) [5] C1(M), with
+    // C1(x) = #{m < x : bit0}, Cany(x) = #{m < x : need != 0}; whole 16-row chunks below the limit, then the partial one
+    const int limB = min(B, M), limN = min(M, m0 + B);
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = tid * 16; c < Mp; c += 1024 * 16) {
+        const u32x4 w = *(const u32x4*)(nl + c);
+        const unsigned long long bal = __ballot((w[0] | w[1] | w[2] | w[3]) != 0u);
+        if ((lane & 7) == 0) tflag[c >> 7] = ((bal >> lane) & 0xffull) != 0ull;
+        u32x4 b0v;
+        int a16 = 0, b16 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b0v[q] = w[q] & 0x01010101u;
+            a16 += __popc((w[q] | (w[q] >> 1)) & 0x01010101u);
+            b16 += __popc(b0v[q]);
+        }
+        cnt[0] += c < m0 ? a16 : 0;
+        cnt[1] += c < m0 ? b16 : 0;
+        cnt[2] += c + 16 <= limB ? b16 : 0;
+        cnt[3] += c + 16 <= limN ? b16 : 0;
+        cnt[4] += a16;
+        cnt[5] += b16;
+        if (c < limB && c + 16 > limB) cnt[2] += popc_low_bytes(b0v, limB - c);
+        if (c < limN && c + 16 > limN) cnt[3] += popc_low_bytes(b0v, limN - c);
+    }
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        const int v = wave_scan64(cnt[l]);
+        if (lane == 63) red[l][wave] = v;
+    }
+    __syncthreads();
+    PREP_STAMP(4);
+    // sums over the 16 waves: lists 0..3 sit in the four DPP rows of one read, lists 4..5 in a second
+    const int* redf = &red[0][0];
+    const int s03 = row_scan16(redf[lane]), s45 = row_scan16(redf[64 + (lane & 31)]);
+    const int C0 = __builtin_amdgcn_readlane(s03, 15), C1 = __builtin_amdgcn_readlane(s03, 31);
+    const int C2 = __builtin_amdgcn_readlane(s03, 47), C3 = __builtin_amdgcn_readlane(s03, 63);
+    const int C4 = __builtin_amdgcn_readlane(s45, 15), C5 = __builtin_amdgcn_readlane(s45, 31);
+    if (first && tid == 0) {
+        nrows[ROWS_ANY] = C4;
+        nrows[ROWS_FWD] = C5 - C2;
+        nrows[ROWS_REV] = C5 - C2;                            // rows m with m + B < M and bit0 of need[m + B]
+    }
+    const int off[3] = {C0, m0 >= B ? C1 - C2 : 0, C3 - C2};
+    const int m = m0 + tid;
+    const int nd = m < M ? nl[m] : 0;
+    const int nn = m + B < M ? nl[m + B] : 0;
+    const int nt = (M + 127) >> 7;
+    const bool flag[4] = {nd != 0, m >= B && (nd & 1), (nn & 1) != 0, tid < nt && tflag[tid < nt ? tid : 0] != 0};
+    int before[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const unsigned long long bal = __ballot(flag[l]);
+        before[l] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[l][wave] = __popcll(bal);
+    }
+    __syncthreads();
+    PREP_STAMP(5);
+    // flags in the waves below this one: the four lists again in the four DPP rows
+    const int wv = (&wsum[0][0])[lane];
+    const int below = row_scan16((lane & 15) < wave ? wv : 0);
+    const int pre[4] = {__builtin_amdgcn_readlane(below, 15), __builtin_amdgcn_readlane(below, 31),
+                        __builtin_amdgcn_readlane(below, 47), __builtin_amdgcn_readlane(below, 63)};
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+        if (flag[l]) rows[(long long)l * M + off[l] + pre[l] + before[l]] = m;
+    if (tiles != nullptr) {
+        if (flag[3] && (tid >> 3) == (int)blockIdx.x) tiles[1 + pre[3] + before[3]] = tid;
+        const int tot = __builtin_amdgcn_readlane(row_scan16(wv), 63);
+        if (first && tid == 0) tiles[0] = tot;
+    }
+    PREP_STAMP(6);
+}
+
 // Packed (permuted) gate column -> row of a torch [4H, *] LSTM parameter, or -1 for padding.
 __device__ __forceinline__ int gate_row(int pc, int H) {
     const int unit = (pc >> 6) * 16 + (pc & 15), gate = (pc & 63) >> 4;

@@ -88,15 +88,32 @@ __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// Wave reductions on DPP row shifts + row broadcasts, result in every lane (v_readlane of lane 63).  A
+// __shfl_xor butterfly is six dependent ds_bpermute round trips through the LDS pipe (~2 us for a block
+// reduction of six counters in k_prep_lists); the small kernels that use these are chains of such latencies.
+// All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float v, float identity) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_or<0x111, 0xf>(v, 0.f);          // row_shr:1
+    v += dpp_or<0x112, 0xf>(v, 0.f);          // row_shr:2
+    v += dpp_or<0x114, 0xf>(v, 0.f);          // row_shr:4
+    v += dpp_or<0x118, 0xf>(v, 0.f);          // row_shr:8   -> lane 15 of each row: the row's sum
+    v += dpp_or<0x142, 0xa>(v, 0.f);          // row_bcast:15 into rows 1 and 3
+    v += dpp_or<0x143, 0xc>(v, 0.f);          // row_bcast:31 into rows 2 and 3 -> lane 63: the wave's sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_or<0x111, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x112, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x114, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x118, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x142, 0xa>(v, -INFINITY));
+    v = fmaxf(v, dpp_or<0x143, 0xc>(v, -INFINITY));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 #endif
 

@@ -973,68 +973,102 @@ __global__ __launch_bounds__(C::NT) void k_lstm_fwd(Shape s, int step, const int
 //   out[m][n] = sum_k A[m][k] * Bt[n][k] + bias[n]
 // AKIND 0: A is fp32 [Mrows][lda].  AKIND 1: A is the [h_fwd(len-1) | h_rev(0)] gather out of Hs
 // (hidden.view(-1,2,B,H)[-1].transpose(0,1).reshape(-1,2H), transfer/models.py:929-934).
+// The shapes are B x {Hp, 2Hp} x {Hp, 2Hp}: a GFLOP and a few MB, so the kernel is a chain of latencies.  The
+// LDS-tiled form (gemm_core: 8-16 k-tiles, each global -> registers -> LDS -> two barriers -> MFMA, 64 x 64 tiles on
+// 128 workgroups) took 9.4 us per product (13.6 with the gather).  Here a workgroup owns a 32 x 64 output tile (256 workgroups at B = 1024) and its eight waves
+// split K: every wave loads its MFMA fragments straight from global memory (16 rows x 64..128 contiguous bytes
+// per load), no LDS and no barrier inside the k loop, and the loads of two k-steps per wave (= 16 of the workgroup) are in flight at once; the
+// eight partial tiles meet in LDS once at the end.  Needs N % 32 == 0 and K % 32 == 0 (Hp is a multiple of 32).
 // ------------------------------------------------------------------------------------------------
-template <class C, int AKIND>
-__global__ __launch_bounds__(C::NT) void k_linear(Shape s, int Mrows, int N, int K, const void* __restrict__ A, int lda,
-                                                 const int* __restrict__ lens, const bf16raw* __restrict__ Bt,
-                                                 const float* __restrict__ bias, float* __restrict__ out, int ldc) {
-    __shared__ __attribute__((aligned(16))) bf16raw As[C::BM * C::LDT];
-    __shared__ __attribute__((aligned(16))) bf16raw Bs[C::BN * C::LDT];
-    const int n0 = blockIdx.x * C::BN, m0 = blockIdx.y * C::BM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f32x4 acc[C::TM][C::TN];
-    zero_acc<C>(acc);
-    if constexpr (AKIND == 0) {
-        const float* Af = (const float*)A;
-        gemm_core<C, RawF32x8>(
-            K,
-            [&](int, int r, int k) {
-                RawF32x8 v;
-                const int m = m0 + r;
-                const bool ok = m < Mrows && k < K;
-                const float* p = Af + (ok ? (long long)m * lda + k : 0ll);
-                v.lo = *(const f32x4*)p;
-                v.hi = *(const f32x4*)(p + 4);
-                if (!ok) v.lo = v.hi = f32x4{0.f, 0.f, 0.f, 0.f};
-                return v;
-            },
-            CvtF32x8(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
-    } else {
-        const bf16raw* Hs = (const bf16raw*)A;
-        const int Hp = s.Hp, B = s.B;
-        // the two source rows of every staging chunk of this thread, resolved once: looking lens[b] up
-        // inside the loader put a dependent load in front of every k-tile's loads
-        const bf16raw* rowp[C::ACH][2];
-        bool rowok[C::ACH];
+constexpr int LKS_BM = 32, LKS_BN = 64, LKS_PITCH = 68, LKS_WAVES = 8;
+constexpr size_t LKS_LDS = (size_t)LKS_WAVES * LKS_BM * LKS_PITCH * 4;
+template <int AKIND>
+__global__ __launch_bounds__(64 * LKS_WAVES) void k_linear_ks(Shape s, int Mrows, int N, int K, const void* __restrict__ A, int lda,
+                                                            const int* __restrict__ lens, const bf16raw* __restrict__ Bt,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) float lks_part[];      // [LKS_WAVES][LKS_BM * LKS_PITCH]
+    const int n0 = blockIdx.x * LKS_BN, m0 = blockIdx.y * LKS_BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
+    const int nks = K >> 5, ks0 = wave * nks / LKS_WAVES, ks1 = (wave + 1) * nks / LKS_WAVES;
+    const int Hp = s.Hp;
+    // fragment rows of this lane: two of A (m), four of Bt (n); rows outside the matrix read row 0 and count as zero
+    const float* apf[2];
+    const bf16raw* aph[2][2];
+    bool aok[2], bok[4];
+    const bf16raw* bp[4];
 #pragma unroll
-        for (int i = 0; i < C::ACH; ++i) {
-            const int b = m0 + tid / C::CH + i * C::RSTEP;
-            const int len = b < Mrows ? lens[b] : 0;
-            rowok[i] = len > 0;
-            const int bb = rowok[i] ? b : 0, ts = rowok[i] ? len - 1 : 0;
-            rowp[i][0] = Hs + (((long long)ts * B + bb) * 2 + 0) * Hp;
-            rowp[i][1] = Hs + (((long long)0 * B + bb) * 2 + 1) * Hp;
+    for (int tm = 0; tm < 2; ++tm) {
+        const int m = m0 + tm * 16 + r;
+        if constexpr (AKIND == 0) {
+            aok[tm] = m < Mrows;
+            apf[tm] = (const float*)A + (aok[tm] ? (long long)m * lda : 0ll) + kq * 8;
+        } else {
+            const int len = m < Mrows ? lens[m] : 0;
+            aok[tm] = len > 0;
+            const int bb = aok[tm] ? m : 0, ts = aok[tm] ? len - 1 : 0;
+            aph[tm][0] = (const bf16raw*)A + (((long long)ts * s.B + bb) * 2 + 0) * Hp + kq * 8;
+            aph[tm][1] = (const bf16raw*)A + (((long long)0 * s.B + bb) * 2 + 1) * Hp + kq * 8;
         }
-        gemm_core<C, u32x4>(
-            K,
-            [&](int i, int, int k) {
-                const int d = k >= Hp ? 1 : 0, kk = k - d * Hp;
-                return load_row(d ? rowp[i][1] : rowp[i][0], rowok[i] && k < K, Hs, kk);
-            },
-            Ident(), [&](int, int r, int k) { return load_packed(Bt, K, n0 + r, N, k, K); }, acc, As, Bs);
     }
-    const int wm = wave / C::WN, wn = wave % C::WN;
 #pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        const int m = m0 + frag_row<C>(wm, tm, lane);
+    for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + tn * 16 + r;
+        bok[tn] = n < N;
+        bp[tn] = Bt + (bok[tn] ? (long long)n * K : 0ll) + kq * 8;
+    }
+    f32x4 acc[2][4];
 #pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int n = n0 + frag_col<C>(wn, tn, lane);
-            if (m < Mrows && n < N) {
-                f32x4 v = acc[tm][tn];
-                if (bias != nullptr) v += *(const f32x4*)&bias[n];
-                *(f32x4*)&out[(long long)m * ldc + n] = v;
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // two k-steps per round, all 16 loads of a round requested before the first MFMA (branch-free: an odd last
+    // step is loaded twice and its second copy zeroed)
+    for (int ks = ks0; ks < ks1; ks += 2) {
+        const bool two = ks + 1 < ks1;
+        const int kk[2] = {ks << 5, (two ? ks + 1 : ks) << 5};
+        u32x4 af[2][2], bfr[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                if constexpr (AKIND == 0) {
+                    af[h][tm] = pack_bf16x8(*(const f32x4*)(apf[tm] + kk[h]), *(const f32x4*)(apf[tm] + kk[h] + 4));
+                } else {
+                    const int d = kk[h] >= Hp ? 1 : 0;            // [h_fwd(len-1) | h_rev(0)]
+                    af[h][tm] = *(const u32x4*)((d ? aph[tm][1] : aph[tm][0]) + (kk[h] - d * Hp));
+                }
+                if (!aok[tm] || (h == 1 && !two)) af[h][tm] = u32x4{0u, 0u, 0u, 0u};
             }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                bfr[h][tn] = *(const u32x4*)(bp[tn] + kk[h]);
+                if (!bok[tn]) bfr[h][tn] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[h][tn]),
+                                                                          __builtin_bit_cast(bf16x8, af[h][tm]), acc[tm][tn], 0, 0, 0);
+    }
+    float* mine = lks_part + wave * (LKS_BM * LKS_PITCH);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) *(f32x4*)&mine[(tm * 16 + r) * LKS_PITCH + tn * 16 + kq * 4] = acc[tm][tn];
+    __syncthreads();
+    {
+        const int ml = tid >> 4, nl = (tid & 15) * 4;             // 512 threads: one float4 of the 32 x 64 tile each
+        const int m = m0 + ml, n = n0 + nl;
+        if (m < Mrows && n < N) {
+            f32x4 v = *(const f32x4*)&lks_part[ml * LKS_PITCH + nl];
+#pragma unroll
+            for (int w = 1; w < LKS_WAVES; ++w) v += *(const f32x4*)&lks_part[w * (LKS_BM * LKS_PITCH) + ml * LKS_PITCH + nl];
+            if (bias != nullptr) v += *(const f32x4*)&bias[n];
+            *(f32x4*)&out[(long long)m * ldc + n] = v;
         }
     }
 }
@@ -1075,29 +1109,48 @@ __global__ __launch_bounds__(256) void k_attn_fwd(Shape s, const float* __restri
     }
     const float bias_a = ba[0];
     float mx = -INFINITY, l = 0.f;
-    for (int t = wave; t < T; t += 4) {
-        const long long m = (long long)t * B + b;
-        if (!(need[m] & 2)) continue;               // masked position: weight is exactly 0
-        f32x4 kk[NV];
-        float part = 0.f;
+    // The unmasked steps of this wave as a bit mask (lane j looks at t = tb + wave + 4 j; masked positions get
+    // weight exactly 0 and are skipped), then the key rows of up to four steps in flight: a step-by-step loop is
+    // a chain of two dependent global loads (need byte, key row) per step, 16 latencies at T = 32.
+    for (int tb = 0; tb < T; tb += 256) {
+        const int tl = tb + wave + 4 * lane;
+        unsigned long long todo = __ballot(tl < T && (need[(long long)tl * B + b] & 2));
+        while (todo) {
+            int tt[4];
+            f32x4 kk[4][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int h = v * 256 + lane * 4;
-            kk[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (h < Hp) {
-                kk[v] = *(const f32x4*)&Kk[m * Hp + h];
+            for (int k = 0; k < 4; ++k) {
+                tt[k] = -1;
+                if (todo) {
+                    tt[k] = tb + wave + 4 * (int)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const long long m = (long long)tt[k] * B + b;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) part += w[v][e] * tanhf_(kk[v][e] + u[v][e]);
+                    for (int v = 0; v < NV; ++v) {
+                        const int h = v * 256 + lane * 4;
+                        kk[k][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (h < Hp) kk[k][v] = *(const f32x4*)&Kk[m * Hp + h];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (tt[k] < 0) break;
+                float part = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part += w[v][e] * tanhf_(kk[k][v][e] + u[v][e]);   // w = 0 at h >= Hp
+                const float sc_t = wave_sum(part) + bias_a;
+                if (lane == 0) sc[tt[k]] = sc_t;
+                const float mn = fmaxf(mx, sc_t);
+                const float scale = __expf(mx - mn), p = __expf(sc_t - mn);   // exp(-inf) = 0 on the first hit
+                l = l * scale + p;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) cacc[v] = cacc[v] * scale + kk[k][v] * p;
+                mx = mn;
             }
         }
-        const float sc_t = wave_sum(part) + bias_a;
-        if (lane == 0) sc[t] = sc_t;
-        const float mn = fmaxf(mx, sc_t);
-        const float scale = __expf(mx - mn), p = __expf(sc_t - mn);   // exp(-inf) = 0 on the first hit
-        l = l * scale + p;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) cacc[v] = cacc[v] * scale + kk[v] * p;
-        mx = mn;
     }
     if (lane == 0) {
         wm_[wave] = mx;
@@ -1159,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(Shape s, const float* __restri
 // per-sentence pieces of the head's parameter gradients (used only by sad_param_grads):
 // DL = dlogits, DWA[b] = sum_t ds_t * tanh(Kk_t + u)  (d linear_attn.weight), DSSUM[b] = sum_t ds_t.
 // ------------------------------------------------------------------------------------------------
+constexpr int ATT_BWD_INFLIGHT = 2;
 template <int NV>
 __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restrict__ Kk, const float* __restrict__ U,
                                                  const float* __restrict__ wa, const float* __restrict__ wo,
@@ -1177,6 +1231,21 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
     __shared__ __attribute__((aligned(16))) float dux[4][NV * 256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Hp = s.Hp, B = s.B, T = s.T, L = s.L;
+    // everything that does not depend on dlogits is requested before thread 0 works them out (the kernel is a
+    // chain of global-load latencies: ~1 us each, ~10 per sentence)
+    f32x4 u[NV], w[NV], cv[NV], wo0[NV], wo1[NV], dctx[NV], du[NV], dwa[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int h = v * 256 + lane * 4;
+        u[v] = w[v] = cv[v] = wo0[v] = wo1[v] = dctx[v] = du[v] = dwa[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (h < Hp) {
+            u[v] = *(const f32x4*)&U[(long long)b * Hp + h];
+            w[v] = *(const f32x4*)&wa[h];
+            cv[v] = *(const f32x4*)&ctx[(long long)b * Hp + h];
+            wo0[v] = *(const f32x4*)&wo[h];
+            if (L > 1) wo1[v] = *(const f32x4*)&wo[Hp + h];
+        }
+    }
     if (tid == 0) {
         for (int c = 0; c < L; ++c) dl[c] = dlogits != nullptr ? dlogits[(long long)b * L + c] : 0.f;
         if (labels != nullptr && (dlogits == nullptr || dloss != nullptr || dloss_scale != 0.f)) {
@@ -1193,19 +1262,16 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
     }
     __syncthreads();
     if (tid < L) DL[(long long)b * L + tid] = dl[tid];
-    f32x4 u[NV], w[NV], dctx[NV], du[NV], dwa[NV];
     float dpart = 0.f, dssum = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int h = v * 256 + lane * 4;
-        u[v] = w[v] = dctx[v] = du[v] = dwa[v] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (h < Hp) {
-            u[v] = *(const f32x4*)&U[(long long)b * Hp + h];
-            w[v] = *(const f32x4*)&wa[h];
-            for (int c = 0; c < L; ++c) dctx[v] += *(const f32x4*)&wo[(long long)c * Hp + h] * dl[c];
-            const f32x4 cv = *(const f32x4*)&ctx[(long long)b * Hp + h];
+            dctx[v] = wo0[v] * dl[0];
+            if (L > 1) dctx[v] += wo1[v] * dl[1];
+            for (int c = 2; c < L; ++c) dctx[v] += *(const f32x4*)&wo[(long long)c * Hp + h] * dl[c];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dpart += dctx[v][e] * cv[e];
+            for (int e = 0; e < 4; ++e) dpart += dctx[v][e] * cv[v][e];
         }
     }
     // delta = sum_t a_t * da_t = dctx . ctx (+ sum_t a_t * dweights_t); every wave computes it.
@@ -1215,45 +1281,71 @@ __global__ __launch_bounds__(256) void k_attn_bwd(Shape s, const float* __restri
             if (a > 0.f) dpart += a * dweights[(long long)b * T + t];
         }
     const float delta = wave_sum(dpart);
-    for (int t = wave; t < T; t += 4) {
-        const long long m = (long long)t * B + b;
-        bf16raw* dz = DZ + m * s.Ncat + 2 * s.Gp;
-        const float a = weights[(long long)b * T + t];
-        if (!(a > 0.f)) {   // masked (exact 0), underflowed, or NaN row
+    // Lane j holds the attention weight (and its upstream gradient) of step t = tb + wave + 4 j; the steps with a
+    // positive weight are worked through with the key rows of ATT_BWD_INFLIGHT of them in flight (see k_attn_fwd;
+    // four in flight need 134 VGPRs: three workgroups per CU instead of four, two rounds at B = 1024: 22 us vs 20).
+    for (int tb = 0; tb < T; tb += 256) {
+        const int tl = tb + wave + 4 * lane;
+        const float a_l = tl < T ? weights[(long long)b * T + tl] : 0.f;
+        const float dw_l = tl < T && dweights != nullptr ? dweights[(long long)b * T + tl] : 0.f;
+        unsigned long long todo = __ballot(a_l > 0.f);
+        unsigned long long zero = __ballot(tl < T && !(a_l > 0.f));   // masked (exact 0), underflowed, or NaN row
+        while (zero) {
+            const int t = tb + wave + 4 * (int)__builtin_ctzll(zero);
+            zero &= zero - 1;
+            bf16raw* dz = DZ + ((long long)t * B + b) * s.Ncat + 2 * s.Gp;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int h = v * 256 + lane * 4;
                 if (h < Hp) *(u32x2*)&dz[h] = u32x2{0u, 0u};
             }
-            continue;
         }
-        f32x4 kk[NV], mid[NV];
-        float part = 0.f;
+        while (todo) {
+            int jj[ATT_BWD_INFLIGHT];
+            f32x4 kk[ATT_BWD_INFLIGHT][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int h = v * 256 + lane * 4;
-            kk[v] = mid[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (h < Hp) {
-                kk[v] = *(const f32x4*)&Kk[m * Hp + h];
+            for (int k = 0; k < ATT_BWD_INFLIGHT; ++k) {
+                jj[k] = -1;
+                if (todo) {
+                    jj[k] = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const long long m = (long long)(tb + wave + 4 * jj[k]) * B + b;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    mid[v][e] = tanhf_(kk[v][e] + u[v][e]);
-                    part += dctx[v][e] * kk[v][e];
+                    for (int v = 0; v < NV; ++v) {
+                        const int h = v * 256 + lane * 4;
+                        kk[k][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (h < Hp) kk[k][v] = *(const f32x4*)&Kk[m * Hp + h];
+                    }
                 }
             }
-        }
-        float da = wave_sum(part);
-        if (dweights != nullptr) da += dweights[(long long)b * T + t];
-        const float ds = a * (da - delta);
-        dssum += ds;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int h = v * 256 + lane * 4;
-            if (h < Hp) {
-                const f32x4 dpre = (1.f - mid[v] * mid[v]) * w[v] * ds;
-                du[v] += dpre;
-                dwa[v] += mid[v] * ds;
-                *(u32x2*)&dz[h] = pack_bf16x4(dctx[v] * a + dpre);
+            for (int k = 0; k < ATT_BWD_INFLIGHT; ++k) {
+                if (jj[k] < 0) break;
+                const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_l), jj[k]));
+                const float dw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dw_l), jj[k]));
+                bf16raw* dz = DZ + ((long long)(tb + wave + 4 * jj[k]) * B + b) * s.Ncat + 2 * s.Gp;
+                f32x4 mid[NV];
+                float part = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        mid[v][e] = tanhf_(kk[k][v][e] + u[v][e]);
+                        part += dctx[v][e] * kk[k][v][e];          // dctx = 0 at h >= Hp
+                    }
+                const float da = wave_sum(part) + dw;
+                const float ds = a * (da - delta);
+                dssum += ds;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int h = v * 256 + lane * 4;
+                    if (h < Hp) {
+                        const f32x4 dpre = (1.f - mid[v] * mid[v]) * w[v] * ds;
+                        du[v] += dpre;
+                        dwa[v] += mid[v] * ds;
+                        *(u32x2*)&dz[h] = pack_bf16x4(dctx[v] * a + dpre);
+                    }
+                }
             }
         }
     }

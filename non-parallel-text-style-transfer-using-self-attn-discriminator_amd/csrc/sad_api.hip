@@ -214,7 +214,6 @@ typedef Cfg<128, 320, 2, 4, 2> CfgWideN;   // 512 threads; all of Ep=320 in one 
 typedef Cfg<64, 320, 2, 4, 2> CfgWideN64;  // K1 forward at small batches: half-height tiles, twice the workgroups
 typedef Cfg<128, 64, 2, 2, 2> CfgNarrowN;
 typedef Cfg<128, 128, 2, 2, 2> CfgSquare;
-typedef Cfg<64, 64, 2, 2, 2> CfgSmall;
 // LSTM steps are small latency-bound GEMMs: 4 K-tiles of loads in flight per workgroup.
 typedef Cfg<128, 128, 4, 2, 4> CfgStepBig;   // 512 threads: 32 rows x one 64-col gate block per wave
 typedef Cfg<64, 64, 4, 1, 4> CfgStepSmall;   // small batch: 16 rows x one gate block per wave
@@ -647,13 +646,14 @@ int run_bridge_fwd(const Ctx& c, const Ctx& top) {
     const bf16raw* Hs = at<bf16raw>(top.ws, top.wl.off[SAD_WS_HS]);
     float* Q = at<float>(c.ws, c.wl.off[SAD_WS_Q]);
     float* U = at<float>(c.ws, c.wl.off[SAD_WS_U]);
-    typedef CfgSmall C;
-    dim3 grid(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
-    hipLaunchKernelGGL((k_linear<C, 1>), grid, dim3(C::NT), 0, c.st, s, s.B, s.Hp, 2 * s.Hp, (const void*)Hs, 0, lens,
+    dim3 grid(ceil_div(s.Hp, LKS_BN), ceil_div(s.B, LKS_BM));
+    allow_lds((const void*)k_linear_ks<1>, LKS_LDS, 64 * LKS_WAVES);
+    allow_lds((const void*)k_linear_ks<0>, LKS_LDS, 64 * LKS_WAVES);
+    hipLaunchKernelGGL(k_linear_ks<1>, grid, dim3(64 * LKS_WAVES), LKS_LDS, c.st, s, s.B, s.Hp, 2 * s.Hp, (const void*)Hs, 0, lens,
                        at<bf16raw>(c.packed, c.pl.whb0), at<float>(c.packed, c.pl.bhb0), Q, s.Hp);
-    hipLaunchKernelGGL((k_linear<C, 0>), grid, dim3(C::NT), 0, c.st, s, s.B, s.Hp, s.Hp, (const void*)Q, s.Hp, lens,
+    hipLaunchKernelGGL(k_linear_ks<0>, grid, dim3(64 * LKS_WAVES), LKS_LDS, c.st, s, s.B, s.Hp, s.Hp, (const void*)Q, s.Hp, lens,
                        at<bf16raw>(c.packed, c.pl.wq), at<float>(c.packed, c.pl.bq), U, s.Hp);
-    SAD_CHECK_LAUNCH("k_linear");
+    SAD_CHECK_LAUNCH("k_linear_ks");
     return 0;
 }
 
@@ -717,14 +717,14 @@ int run_bridge_bwd(const Ctx& c, const Ctx& top) {
     float* DU = at<float>(c.ws, c.wl.off[SAD_WS_DU]);
     float* DQ = at<float>(c.ws, c.wl.off[SAD_WS_DQ]);
     float* DHFIN = at<float>(top.ws, top.wl.off[SAD_WS_DHFIN]);
-    typedef CfgSmall C;
-    dim3 g1(ceil_div(s.Hp, C::BN), ceil_div(s.B, C::BM));
-    hipLaunchKernelGGL((k_linear<C, 0>), g1, dim3(C::NT), 0, c.st, s, s.B, s.Hp, s.Hp, (const void*)DU, s.Hp, lens,
+    dim3 g1(ceil_div(s.Hp, LKS_BN), ceil_div(s.B, LKS_BM));
+    allow_lds((const void*)k_linear_ks<0>, LKS_LDS, 64 * LKS_WAVES);
+    hipLaunchKernelGGL(k_linear_ks<0>, g1, dim3(64 * LKS_WAVES), LKS_LDS, c.st, s, s.B, s.Hp, s.Hp, (const void*)DU, s.Hp, lens,
                        at<bf16raw>(c.packed, c.pl.wqT), (const float*)nullptr, DQ, s.Hp);
-    dim3 g2(ceil_div(2 * s.Hp, C::BN), ceil_div(s.B, C::BM));
-    hipLaunchKernelGGL((k_linear<C, 0>), g2, dim3(C::NT), 0, c.st, s, s.B, 2 * s.Hp, s.Hp, (const void*)DQ, s.Hp, lens,
+    dim3 g2(ceil_div(2 * s.Hp, LKS_BN), ceil_div(s.B, LKS_BM));
+    hipLaunchKernelGGL(k_linear_ks<0>, g2, dim3(64 * LKS_WAVES), LKS_LDS, c.st, s, s.B, 2 * s.Hp, s.Hp, (const void*)DQ, s.Hp, lens,
                        at<bf16raw>(c.packed, c.pl.whb0T), (const float*)nullptr, DHFIN, 2 * s.Hp);
-    SAD_CHECK_LAUNCH("k_linear(bwd)");
+    SAD_CHECK_LAUNCH("k_linear_ks(bwd)");
     return 0;
 }
 

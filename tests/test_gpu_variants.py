@@ -90,7 +90,9 @@ def test_variant_golden(tag):
     loss2, logits2, _ = m.loss(S2.transpose(0, 1), torch.from_numpy(d["lengths"]), mask, lab)
     (loss2.sum() / B).backward()
     assert torch.equal(logits2, logits.detach())
-    assert torch.equal(S2.grad, S.grad)
+    # (the cross-entropy gradient comes from torch above and from k_attn_bwd here: the same numbers up to the
+    # last bits of exp(); run-to-run bit equality of one route is tests/test_gpu_sizes.py's repeatability test)
+    assert (S2.grad - S.grad).abs().max().item() <= 1e-6 * S.grad.abs().max().item()
     # classifier copy, hard tokens, eval mode
     mc = _module("classifier", hdr, params).eval()
     keep = d["cls_keep"]

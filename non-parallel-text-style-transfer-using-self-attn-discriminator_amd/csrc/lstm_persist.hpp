@@ -49,9 +49,13 @@ __device__ __forceinline__ u32x4 lp_pair16(u32x2 x, u32x2 y) {
     const auto s1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
     return u32x4{s0[0], s1[0], s0[1], s1[1]};
 }
-// 16-byte agent-scope (sc1, write-through) store of handed-off payload.
-__device__ __forceinline__ void lp_store16_sc1(bf16raw* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+// 16-byte agent-scope (sc1, write-through) store of handed-off payload, as a buffer store the compiler can see; an
+// offset beyond the descriptor's range drops the store (branch-free row predicate).  It used to be inline asm
+// (`global_store_dwordx4 ... sc1`): the hazard recognizer and the waitcnt pass know nothing of inline asm, and in an
+// experiment with two such stores back to back the compiler put the second one's operand moves right behind the
+// first store, inside the window in which a 16-byte store still reads its registers -- stores went astray.
+__device__ __forceinline__ void lp_store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16 /* sc1 */);
 }
 // Activated gates of the persistent recurrences: fp16 records of [unit][i, f, g, o] (SAD_WS_GA).  The
 // values lie in [-1, 1] (the GRU's fourth slot, W_hn h + b_hn, is O(1)), so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         if (*dead) hv = u32x4{LP_NAN2, LP_NAN2, LP_NAN2, LP_NAN2};   // timed out: never publish results of stale h
         const int tmq = q & 1;
         const bool actq = tmq ? act[1] : act[0];
-        if (actq) lp_store16_sc1(HX + (done & 1) * xpar + (tmq ? xrow[1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u, hv);
+        lp_store16_sc1(lp_rsrc(HX + (done & 1) * xpar, (unsigned)(xpar * 2)),
+                       actq ? ((tmq ? xrow[1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u) * 2u : LP_OOB, hv);
         LF_PROF_T(4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
         LF_PROF_T(5)
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         u32x4 pv[2][2];
         const bool poisoned = *dead != 0u;                   // timed out: never publish results of stale dZ
         {
-            bf16raw* xout = DZX + (done & 1) * xpar + xrow;
+            const __amdgpu_buffer_rsrc_t xout = lp_rsrc(DZX + (done & 1) * xpar, (unsigned)(xpar * 2));
             const int q = lane >> 4;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                     pv[tn][p2] = lp_pair16(pk[tn][2 * p2], pk[tn][2 * p2 + 1]);
                     if (poisoned) pv[tn][p2] = u32x4{LP_NAN2, LP_NAN2, LP_NAN2, LP_NAN2};
                     const int col = (pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8;
-                    if (act) lp_store16_sc1(&xout[(col >> 3) * 128], pv[tn][p2]);
+                    lp_store16_sc1(xout, act ? (xrow + (unsigned)(col >> 3) * 128u) * 2u : LP_OOB, pv[tn][p2]);
                 }
         }
         LB_PROF_T(4)

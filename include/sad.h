@@ -191,7 +191,7 @@ enum sad_ws_field {
     SAD_WS_ROWS,     /* int32 [3][T*B] compacted lists of contributing token rows (in-projection, weight gradients) */
     SAD_WS_NROWS,    /* int32 [4]    their lengths */
     SAD_WS_SYNC,     /* u32: hand-off counters of the persistent recurrence (one 128-B line per sentence
-                        tile and direction), then one line with the timeout words: [0] forward recurrence,
+                        tile and direction; 2 * ceil(B / 32) lines), then one line with the timeout words: [0] forward recurrence,
                         [1] BPTT (non-zero = a hand-off wait timed out; the outputs are NaN then) */
     SAD_WS_DZX,      /* bf16 [2][2][B/16][Gp/8][16][8] hand-off image of dZ inside the persistent BPTT */
     SAD_WS_HX,       /* bf16 [2][2][B/16][Hp/8][16][8] hand-off image of h inside the persistent recurrence */

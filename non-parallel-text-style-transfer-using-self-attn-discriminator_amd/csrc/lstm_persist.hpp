@@ -95,6 +95,9 @@ __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigne
 
 constexpr int LP_BM = 128;                                   // sentences per tile (= LF_BM = LB_BM)
 constexpr int LP_SYNC_PITCH = 32;                            // counter pitch in 4-byte words (128-B lines)
+constexpr int LP_BM_MIN = 32;                                // smallest sentence tile (BPTT at small batches)
+// SAD_WS_SYNC: one counter line per (sentence tile, direction) at the smallest tile, then the line of the timeout words
+__host__ __device__ inline int lp_err_line(int B) { return 2 * ((B + LP_BM_MIN - 1) / LP_BM_MIN); }
 constexpr unsigned LP_SPIN_LIMIT = 1u << 22;                 // default bound of a hand-off wait (~seconds)
 constexpr unsigned LP_NAN2 = 0x7fc07fc0u;                    // two bf16 quiet NaNs
 
@@ -157,7 +160,7 @@ __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
 #define LF_PROF_T(i) pt[i] = wall_clock64();
 #define LF_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0][0]), "v"(acc[1][3][0])); }
 #define LF_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; }
-#define LF_PROF_OUT if (tid == 0 && group == SAD_LF_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)groups * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; }
+#define LF_PROF_OUT if (tid == 0 && group == SAD_LF_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)lp_err_line(s.B) * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; }
 #else
 #define LF_PROF_DECL
 #define LF_PROF_T(i)
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     }
     const int dir = group & 1, b0 = (group >> 1) * LF_BM, n0 = ct * LF_BN;
     gu32* counter = (gu32*)(sync + (size_t)group * LP_SYNC_PITCH);
-    gu32* errword = (gu32*)(sync + (size_t)groups * LP_SYNC_PITCH);
+    gu32* errword = (gu32*)(sync + (size_t)lp_err_line(B) * LP_SYNC_PITCH);
     const int cpr = Hp / 8;                                  // 16-byte chunks per W row
     const int cmask = (cpr % 16 == 0) ? 15 : 3;
     {
@@ -407,6 +410,15 @@ namespace sad {
 #endif
 constexpr int LB_BM = 128, LB_BN = 32, LB_SG_MAX = 16, LB_NS = SAD_LB_NS;       // Gp <= 128 * LB_SG_MAX
 
+// Sentence tile of the BPTT.  A workgroup reads tile x Gp x 2 bytes of handed-off dZ per step at the ~70 GB/s a CU
+// gets from sc1-stored payload (B = 64: 256 KB, 3.7 us of a 5.8 us step), and at B < 1024 the 128-sentence tiling
+// leaves CUs empty: take the smallest tile whose grid still fits one workgroup per CU.
+__host__ __device__ inline int lstm_bwd_tile(int B, int Hp, int cus) {
+    const int ctiles = Hp / LB_BN;
+    for (int bm = LP_BM_MIN; bm < LB_BM; bm *= 2)
+        if (2 * ((B + bm - 1) / bm) * ctiles <= cus) return bm;
+    return LB_BM;
+}
 __host__ __device__ inline size_t lstm_bwd_persist_lds_bytes(int Gp) { return (size_t)LB_BN * Gp * 2 + 16; }
 // Hand-off image of dZ between the workgroups of a group, two step parities: laid out so that the 16
 // lanes of a quarter wave (16 sentences, one 8-column chunk = one MFMA fragment piece each) touch 256
@@ -423,7 +435,7 @@ __host__ __device__ inline size_t lstm_bwd_xchg_bytes(int B, int Gp) {
 #define LB_PROF_T(i) pt[i] = wall_clock64();
 #define LB_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0]), "v"(acc[1][0])); }
 #define LB_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; if (p_last6) p_gap += pt[0] - p_last6; } p_last6 = pt[6];
-#define LB_PROF_OUT if (tid == 0 && group == SAD_LB_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)groups * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; o[7] = p_loop - p_entry; o[8] = wall_clock64() - p_entry; o[9] = p_gap; }
+#define LB_PROF_OUT if (tid == 0 && group == SAD_LB_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)lp_err_line(s.B) * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; o[7] = p_loop - p_entry; o[8] = wall_clock64() - p_entry; o[9] = p_gap; }
 #else
 #define LB_PROF_ENTRY
 #define LB_PROF_DECL
@@ -437,14 +449,15 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
                                                          bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync,
                                                          unsigned spin_limit, int withhold,
-                                                         const bf16raw* __restrict__ DHS, int ldh) {
+                                                         const bf16raw* __restrict__ DHS, int ldh, int bm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
     LB_PROF_ENTRY
     bf16raw* Wl = (bf16raw*)lp_lds;                                  // [32][Gp], chunk-swizzled
     if ((int)blockIdx.x == withhold) return;                         // test hook: this workgroup never signals
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ctiles = Hp / LB_BN, rtiles = (B + LB_BM - 1) / LB_BM, groups = rtiles * 2;
+    // bm: sentences per tile (LB_BM, or 64 / 32 at small batches: waves 16 w >= bm idle -- see lstm_bwd_tile)
+    const int ctiles = Hp / LB_BN, rtiles = (B + bm - 1) / bm, groups = rtiles * 2;
     int group, ct;
     if ((gridDim.x / ctiles) % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only; see the forward kernel)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -455,9 +468,9 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         group = blockIdx.x / ctiles;
         ct = blockIdx.x % ctiles;
     }
-    const int dir = group & 1, b0 = (group >> 1) * LB_BM, j0 = ct * LB_BN;
+    const int dir = group & 1, b0 = (group >> 1) * bm, j0 = ct * LB_BN;
     gu32* counter = (gu32*)(sync + (size_t)group * LP_SYNC_PITCH);
-    gu32* errword = (gu32*)(sync + (size_t)groups * LP_SYNC_PITCH + 1);
+    gu32* errword = (gu32*)(sync + (size_t)lp_err_line(B) * LP_SYNC_PITCH + 1);
     const int cpr = Gp / 8;                                          // 16-byte chunks per W row (multiple of 16)
 
     // ---- once: W_hh^T slice -> LDS; longest sentence of the tile -----------------------------------
@@ -474,13 +487,14 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         int* red_max = (int*)(lp_lds + (size_t)LB_BN * Gp * 2);
         if (tid == 0) { *red_max = 0; *dead = 0u; }
         __syncthreads();
-        if (tid < LB_BM && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
+        if (tid < bm && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
         __syncthreads();
         maxlen = *red_max;
     }
     // this lane: sentence b0 + 16*wave + (lane & 15); unit quads j0 + 16*tn + 4*(lane >> 4), tn = 0, 1
     const int b = b0 + wave * 16 + (lane & 15);
-    const int len = b < B ? lens[b] : 0;
+    const bool mine = wave * 16 < bm && b < B;
+    const int len = mine ? lens[b] : 0;
     int ju[2], pcu[2];
     f32x4 dcreg[2];
 #pragma unroll
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     }
     const int nsg = Gp / 128;                                // fragment sets of 4 x 32 k
     // hand-off image of dZ (see lstm_bwd_xchg_bytes): [parity][dir][16-sentence block][8-column chunk][16][8]
-    const int sblocks = rtiles * (LB_BM / 16);
+    const int sblocks = rtiles * (bm / 16);
     const size_t xpar = (size_t)2 * sblocks * Gp * 16;       // elements of one parity
     const unsigned xrow = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave) * (Gp / 8) * 128 + (lane & 15) * 8);
     unsigned done = 0;
@@ -553,7 +567,8 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();
             LB_PROF_T(2)
-            // ---- dh = dZ_{tn} . W_hh for this wave's 16 sentences ------------------------------------
+            // ---- dh = dZ_{tn} . W_hh for this wave's 16 sentences (a wave without sentences skips it) --
+            if (wave * 16 < bm && b0 + wave * 16 < B) {
             const bool rowok = len > tn_ && act;
             const __amdgpu_buffer_rsrc_t rs = lp_rsrc(DZX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
             const unsigned voff = rowok ? (xrow + (unsigned)(lane >> 4) * 128u) * 2u : LP_OOB;
@@ -587,6 +602,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                     mma_set(sg + i, f[i]);
                     load_set(sg + LB_NS + i, f[i]);
                 }
+            }
             }
         }
         LB_PROF_ACC
@@ -676,7 +692,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     // dZ rows of padded steps (t >= len) are exact zeros: later kernels read every row of DZ.  Done
     // after the recurrence: tiles of short sentences have the most of these rows and finish their
     // steps first, so the stores no longer sit in front of the first hand-offs of the long tiles.
-    if (b < B) {
+    if (mine) {
         for (int t = len; t < T; ++t) {
             bf16raw* zrow = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
 #pragma unroll

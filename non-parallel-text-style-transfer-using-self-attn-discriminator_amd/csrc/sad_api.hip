@@ -166,7 +166,7 @@ WsLayout ws_layout(const Shape& s) {
     w.bytes[SAD_WS_DSSUM] = B * 4;
     w.bytes[SAD_WS_ROWS] = M * 3 * 4;
     w.bytes[SAD_WS_NROWS] = 4 * 4;
-    w.bytes[SAD_WS_SYNC] = ((size_t)2 * ceil_div(s.B, LP_BM) + 1) * LP_SYNC_PITCH * 4;
+    w.bytes[SAD_WS_SYNC] = ((size_t)lp_err_line(s.B) + 1) * LP_SYNC_PITCH * 4;
     w.bytes[SAD_WS_DZX] = lstm_bwd_xchg_bytes(s.B, s.Gp);
     w.bytes[SAD_WS_HX] = lstm_fwd_xchg_bytes(s.B, s.Hp);
     w.bytes[SAD_WS_GA] = ga_bytes(s.T, s.B, s.Hp);
@@ -387,7 +387,8 @@ bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
-    const int groups = 2 * ceil_div(s.B, LB_BM), ctiles = s.Hp / LB_BN;
+    const int bm = lstm_bwd_tile(s.B, s.Hp, device_cus());
+    const int groups = 2 * ceil_div(s.B, bm), ctiles = s.Hp / LB_BN;
     *grid = ceil_to(groups, 8) * ctiles;
     if (persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512)) return true;
     *grid = groups * ctiles;
@@ -670,7 +671,7 @@ int run_attn_fwd(const Ctx& c, const int64_t* labels, float* logits, float* weig
     const float* bo = at<float>(c.packed, c.pl.bo);
     const long long* lab = (const long long*)labels;
     // timeout word of the forward recurrence (behind the hand-off counters)
-    const unsigned* err = at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]) + (size_t)2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH;
+    const unsigned* err = at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]) + (size_t)lp_err_line(s.B) * LP_SYNC_PITCH;
 #define SAD_ATT_FWD(NV)                                                                                             \
     hipLaunchKernelGGL((k_attn_fwd<NV>), dim3(s.B), dim3(256), 0, c.st, s, Kk, U, need, wa, ba, wo, bo, lab, weights, CTX, \
                        logits, loss, err)
@@ -699,7 +700,7 @@ int run_attn_bwd(const Ctx& c, const sad_bwd_args* a) {
                        lab, a->dlogits, a->dloss, a->dloss_scale, a->dweights, DZ, DU,                                \
                        at<float>(c.ws, c.wl.off[SAD_WS_DL]), at<float>(c.ws, c.wl.off[SAD_WS_DWA]),                   \
                        at<float>(c.ws, c.wl.off[SAD_WS_DSSUM]), at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]),            \
-                       2 * ceil_div(s.B, LP_BM) * LP_SYNC_PITCH)
+                       lp_err_line(s.B) * LP_SYNC_PITCH)
     if (s.Hp <= 256) SAD_ATT_BWD(1);
     else if (s.Hp <= 512) SAD_ATT_BWD(2);
     else if (s.Hp <= 1024) SAD_ATT_BWD(4);
@@ -748,7 +749,7 @@ int run_lstm_bwd(const Ctx& c, const bf16raw* dhs = nullptr, int ldh = 0) {
                            Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
-                           g_withhold_bwd.load(std::memory_order_relaxed), dhs, ldh);
+                           g_withhold_bwd.load(std::memory_order_relaxed), dhs, ldh, lstm_bwd_tile(s.B, s.Hp, device_cus()));
     } else {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;
@@ -817,7 +818,7 @@ int run_apply_keep(const Ctx& c, bf16raw* x, const uint8_t* keep, float scale) {
 // Stage entry points run without the kernel that normally zeroes the hand-off counters in front of a
 // recurrence: a 256-byte-multiple memset on the same stream does it (counters only, or + timeout words).
 int run_zero_sync(const Ctx& c, bool with_timeout_words) {
-    const size_t counters = (size_t)2 * ceil_div(c.s.B, LP_BM) * LP_SYNC_PITCH * 4;
+    const size_t counters = (size_t)lp_err_line(c.s.B) * LP_SYNC_PITCH * 4;
     const size_t n = with_timeout_words ? c.wl.bytes[SAD_WS_SYNC] : counters;
     if (hipMemsetAsync(at<unsigned char>(c.ws, c.wl.off[SAD_WS_SYNC]), 0, n, c.st) != hipSuccess)
         return fail(-2, "hipMemsetAsync(SYNC) failed");

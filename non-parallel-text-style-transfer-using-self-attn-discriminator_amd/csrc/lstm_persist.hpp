@@ -149,6 +149,14 @@ namespace sad {
 #endif
 constexpr int LF_BM = 128, LF_BN = 64, LF_KS_MAX = 16, LF_NS = SAD_LF_NS;   // Hp <= 32 * LF_KS_MAX
 
+// Sentence tile of the forward recurrence: the smallest of 32 / 64 / 128 whose grid still fits `slots` co-resident
+// workgroups (two per CU), so that small batches spread over the CUs (see lstm_bwd_tile).
+__host__ __device__ inline int lstm_fwd_tile(int B, int Gp, int slots) {
+    const int ctiles = Gp / LF_BN;
+    for (int bm = LP_BM_MIN; bm < LF_BM; bm *= 2)
+        if (2 * ((B + bm - 1) / bm) * ctiles <= slots) return bm;
+    return LF_BM;
+}
 __host__ __device__ inline size_t lstm_fwd2_lds_bytes(int Hp) { return (size_t)LF_BN * Hp * 2 + 16; }
 __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
     return (size_t)2 * 2 * ((B + LF_BM - 1) / LF_BM * LF_BM) * Hp * 2;
@@ -172,13 +180,14 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
                                                           unsigned short* __restrict__ GA, unsigned* sync,
-                                                          unsigned spin_limit, int withhold) {
+                                                          unsigned spin_limit, int withhold, int bm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
     bf16raw* Wl = (bf16raw*)lp_lds;                          // [64][Hp], chunk-swizzled
     if ((int)blockIdx.x == withhold) return;                 // test hook: this workgroup never signals
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ctiles = Gp / LF_BN, rtiles = (B + LF_BM - 1) / LF_BM, groups = rtiles * 2;
+    // bm: sentences per tile (LF_BM, or 64 / 32 at small batches: waves 32 w >= bm idle -- see lstm_fwd_tile)
+    const int ctiles = Gp / LF_BN, rtiles = (B + bm - 1) / bm, groups = rtiles * 2;
     int group, ct;
     if ((gridDim.x / ctiles) % 8 == 0) {
         // blocks b, b+8, ... share an XCD (speed only): keep a group on one XCD, so that its hand-offs are served
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         group = blockIdx.x / ctiles;
         ct = blockIdx.x % ctiles;
     }
-    const int dir = group & 1, b0 = (group >> 1) * LF_BM, n0 = ct * LF_BN;
+    const int dir = group & 1, b0 = (group >> 1) * bm, n0 = ct * LF_BN;
     gu32* counter = (gu32*)(sync + (size_t)group * LP_SYNC_PITCH);
     gu32* errword = (gu32*)(sync + (size_t)lp_err_line(B) * LP_SYNC_PITCH);
     const int cpr = Hp / 8;                                  // 16-byte chunks per W row
@@ -210,13 +219,13 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         int* red_max = (int*)(lp_lds + (size_t)LF_BN * Hp * 2);
         if (tid == 0) { *red_max = 0; *dead = 0u; }
         __syncthreads();
-        if (tid < LF_BM && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
+        if (tid < bm && b0 + tid < B) atomicMax(red_max, lens[b0 + tid]);
         __syncthreads();
         maxlen = *red_max;
     }
     const int q = lane >> 4, u4 = q * 4;
     const int j = ct * 16 + u4;                              // first of this lane's 4 hidden units
-    const int sblocks = rtiles * (LF_BM / 16);
+    const int sblocks = rtiles * (bm / 16);
     const size_t xpar = (size_t)2 * sblocks * Hp * 16;       // elements of one parity of the image
     int brow[2], blen[2];
     unsigned xrow[2];                                        // image offset (elements) of this lane's sentence, chunk 0
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
         brow[tm] = b0 + wave * 32 + tm * 16 + (lane & 15);
-        blen[tm] = brow[tm] < B ? lens[brow[tm]] : 0;
+        blen[tm] = (wave * 32 + tm * 16 < bm && brow[tm] < B) ? lens[brow[tm]] : 0;
         creg[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
         xrow[tm] = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave * 2 + tm) * cpr * 128 + (lane & 15) * 8);
     }
@@ -260,6 +269,8 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
             LF_PROF_T(2)
             // ---- h_{tp} of this wave's 32 sentences: LF_NS sets of 4 k-steps (4 KB per wave each) in flight,
             //      16-byte sc1 loads straight into MFMA fragment registers; gates += h_{tp} . W_hh^T
+            //      (a wave without sentences skips it)
+            if (wave * 32 < bm && b0 + wave * 32 < B) {
             const __amdgpu_buffer_rsrc_t rs = lp_rsrc(HX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
             unsigned voff[2];
 #pragma unroll
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                     mma_set(sl, sg + I);
                     load_set(sl, sg + LF_NS + I);
                 });
+            }
             }
         }
         LF_PROF_ACC

@@ -375,11 +375,15 @@ bool persist_fits(const void* kernel, size_t lds, int grid, int threads) {
     return per_cu >= 1 && grid <= per_cu * device_cus();
 }
 // forward recurrence: half-width workgroups, two per CU
+int lstm_fwd_bm(const Shape& s) {
+    const int per_cu = kernel_per_cu((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), 256);
+    return lstm_fwd_tile(s.B, s.Gp, (per_cu < 1 ? 1 : per_cu) * device_cus());
+}
 bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
     if (s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
     if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
     // groups padded to a multiple of 8 (one XCD per group, see the kernel) when that still fits
-    const int groups = 2 * ceil_div(s.B, LF_BM), ctiles = s.Gp / LF_BN;
+    const int groups = 2 * ceil_div(s.B, lstm_fwd_bm(s)), ctiles = s.Gp / LF_BN;
     *grid = ceil_to(groups, 8) * ctiles;
     if (persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256)) return true;
     *grid = groups * ctiles;
@@ -621,7 +625,7 @@ int run_lstm_fwd(const Ctx& c) {
                            Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
-                           g_withhold_fwd.load(std::memory_order_relaxed));
+                           g_withhold_fwd.load(std::memory_order_relaxed), lstm_fwd_bm(s));
     } else {
         for (int step = 0; step < s.T; ++step) {
             if (s.B >= 512) {

@@ -1255,29 +1255,27 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         }
         SAD_CHECK_LAUNCH("k_wgrad_dense");
     }
-    // small reductions over sentences
+    // small reductions over sentences: one launch (short serial sums: the kernel is a latency chain)
     {
-        auto colsum = [&](const float* srcp, int cols, int ld, float* dst) {
-            if (dst == nullptr) return;
-            int zs = ceil_div(s.B, 16);          // short serial sums: the kernel is a latency chain
-            if (zs > 256) zs = 256;
-            const int chunk = ceil_div(s.B, zs);
-            hipLaunchKernelGGL(k_colsum_f32, dim3(ceil_div(cols, 256), ceil_div(s.B, chunk)), dim3(256), 0, st, srcp, s.B, cols,
-                               ld, chunk, dst);
-        };
-        colsum(DQ, s.H, s.Hp, g->hidden_bridge0_bias);
-        colsum(DU, s.H, s.Hp, g->linear_q_bias);
-        colsum(DWA, s.H, s.Hp, g->linear_attn_weight);
-        colsum(DSSUM, 1, 1, g->linear_attn_bias);
-        colsum(DL, s.L, s.L, g->output_layer_bias);
-        if (g->output_layer_weight != nullptr) {
-            int zs = ceil_div(s.B, 16);
-            if (zs > 256) zs = 256;
-            const int chunk = ceil_div(s.B, zs);
-            hipLaunchKernelGGL(k_wgrad_head, dim3(ceil_div(s.H, 256), ceil_div(s.B, chunk)), dim3(256), 0, st, s, DL, CTX, chunk,
-                               g->output_layer_weight);
+        ColsumJobs jobs;
+        const float* srcs[5] = {DQ, DU, DWA, DSSUM, DL};
+        float* dsts[5] = {g->hidden_bridge0_bias, g->linear_q_bias, g->linear_attn_weight, g->linear_attn_bias, g->output_layer_bias};
+        const int cols[5] = {s.H, s.H, s.H, 1, s.L}, lds[5] = {s.Hp, s.Hp, s.Hp, 1, s.L};
+        int maxc = s.H;
+        for (int i = 0; i < 5; ++i) {
+            jobs.src[i] = srcs[i];
+            jobs.dst[i] = dsts[i];
+            jobs.cols[i] = cols[i];
+            jobs.ld[i] = lds[i];
+            if (cols[i] > maxc) maxc = cols[i];
         }
-        SAD_CHECK_LAUNCH("k_colsum_f32");
+        jobs.n = 5;
+        int zs = ceil_div(s.B, 16);
+        if (zs > 256) zs = 256;
+        const int chunk = ceil_div(s.B, zs);
+        hipLaunchKernelGGL(k_colsum_small, dim3(ceil_div(maxc, 256), ceil_div(s.B, chunk), 6), dim3(256), 0, st, s, jobs, chunk,
+                           DL, CTX, g->output_layer_weight);
+        SAD_CHECK_LAUNCH("k_colsum_small");
     }
     return 0;
 }

@@ -809,29 +809,37 @@ __global__ __launch_bounds__(128) void k_colsum_dz(Shape s, const bf16raw* __res
     }
 }
 
-// dst[c] += sum_r src[r][c], c < cols.  grid: (ceil(cols/256), row splits)
-__global__ __launch_bounds__(256) void k_colsum_f32(const float* __restrict__ src, int rows, int cols, int ld, int rchunk,
-                                                   float* __restrict__ dst) {
+// The small reductions over sentences of sad_param_grads in ONE launch (six dependent launches of ~4.6 us each
+// before): jobs 0..n-1: dst[c] += sum_b src[b][c], c < cols; the last grid slice (when gwo != NULL):
+// d output_layer.weight [L,H] += dl^T . ctx (transfer/models.py:949).  grid: (ceil(max cols / 256), row splits, n + 1)
+struct ColsumJobs {
+    const float* src[5];
+    float* dst[5];
+    int cols[5], ld[5];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_colsum_small(Shape s, ColsumJobs jobs, int rchunk, const float* __restrict__ DL,
+                                                     const float* __restrict__ CTX, float* __restrict__ gwo) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    const int r0 = blockIdx.y * rchunk, r1 = min(rows, r0 + rchunk);
-    float a = 0.f;
-#pragma unroll 8
-    for (int r = r0; r < r1; ++r) a += src[(long long)r * ld + c];
-    unsafeAtomicAdd(dst + c, a);
-}
-
-// d output_layer.weight [L,H] += dl^T . ctx  (transfer/models.py:949).  grid: (ceil(H/256), row splits)
-__global__ __launch_bounds__(256) void k_wgrad_head(Shape s, const float* __restrict__ DL, const float* __restrict__ CTX,
-                                                   int rchunk, float* __restrict__ gwo) {
-    const int h = blockIdx.x * 256 + threadIdx.x;
-    if (h >= s.H) return;
     const int r0 = blockIdx.y * rchunk, r1 = min(s.B, r0 + rchunk);
-    for (int c = 0; c < s.L; ++c) {
+    const int z = blockIdx.z;
+    if (z < jobs.n) {
+        const float* src = jobs.src[z];
+        float* dst = jobs.dst[z];
+        const int cols = jobs.cols[z], ld = jobs.ld[z];
+        if (dst == nullptr || c >= cols) return;
         float a = 0.f;
 #pragma unroll 8
-        for (int b = r0; b < r1; ++b) a += DL[(long long)b * s.L + c] * CTX[(long long)b * s.Hp + h];
-        unsafeAtomicAdd(gwo + (long long)c * s.H + h, a);
+        for (int r = r0; r < r1; ++r) a += src[(long long)r * ld + c];
+        unsafeAtomicAdd(dst + c, a);
+    } else {
+        if (gwo == nullptr || c >= s.H) return;
+        for (int l = 0; l < s.L; ++l) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int b = r0; b < r1; ++b) a += DL[(long long)b * s.L + l] * CTX[(long long)b * s.Hp + c];
+            unsafeAtomicAdd(gwo + (long long)l * s.H + c, a);
+        }
     }
 }
 

@@ -1203,18 +1203,27 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         }
         SAD_CHECK_LAUNCH("k_wgrad_emb");
     }
-    // d rnn.weight_ih (both directions), d linear_emb.weight
+    // d rnn.weight_ih (both directions), d linear_emb.weight; with a padding column in X (E < Ep) also the LSTM
+    // biases and linear_emb.bias (column sums of DZ: see k_wgrad_cat)
+    const bool want_bias = g->rnn_bias_ih[0] != nullptr || g->rnn_bias_ih[1] != nullptr || g->rnn_bias_hh[0] != nullptr ||
+                           g->rnn_bias_hh[1] != nullptr || g->linear_emb_bias != nullptr;
+    bool bias_done = false;
     if (g->rnn_weight_ih[0] != nullptr || g->rnn_weight_ih[1] != nullptr || g->linear_emb_weight != nullptr) {
+        CatBias cb = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (want_bias && s.E < s.Ep) {
+            cb = CatBias{g->rnn_bias_ih[0], g->rnn_bias_hh[0], g->rnn_bias_ih[1], g->rnn_bias_hh[1], g->linear_emb_bias};
+            bias_done = true;
+        }
         if (s.Ep == 320) {
             typedef WCfg<64, 320, 2, 4> W;
             const int t1 = ceil_div(s.Ncat, W::BN1);
             launch_wg<W>(k_wgrad_cat<W>, dim3(t1, 1, row_split(s.M, t1)), st, s, DZ, X, rows, nrows, g->rnn_weight_ih[0],
-                         g->rnn_weight_ih[1], g->linear_emb_weight);
+                         g->rnn_weight_ih[1], g->linear_emb_weight, cb);
         } else {
             typedef WCfg<128, 64, 4, 1> W;
             const int t1 = ceil_div(s.Ncat, W::BN1), t2 = ceil_div(s.Ep, W::BN2);
             launch_wg<W>(k_wgrad_cat<W>, dim3(t1, t2, row_split(s.M, t1 * t2)), st, s, DZ, X, rows, nrows,
-                         g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight);
+                         g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight, cb);
         }
         SAD_CHECK_LAUNCH("k_wgrad_cat");
     }
@@ -1226,9 +1235,8 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
                      g->rnn_weight_hh[0], g->rnn_weight_hh[1]);
         SAD_CHECK_LAUNCH("k_wgrad_hh");
     }
-    // LSTM biases and linear_emb.bias: column sums of DZ
-    if (g->rnn_bias_ih[0] != nullptr || g->rnn_bias_ih[1] != nullptr || g->rnn_bias_hh[0] != nullptr ||
-        g->rnn_bias_hh[1] != nullptr || g->linear_emb_bias != nullptr) {
+    // LSTM biases and linear_emb.bias: column sums of DZ (when they did not ride along above)
+    if (want_bias && !bias_done) {
         const int cb = ceil_div(s.Ncat, 1024);
         int zs = ceil_div(512, cb);                         // row splits (whole 64-row pieces of the compacted list)
         if (zs > ceil_div(s.M, 64)) zs = ceil_div(s.M, 64);

@@ -68,8 +68,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int pitch) {
 //   * the loop issues a STATIC number of memory operations, so hipcc keeps counted
 //     s_waitcnt vmcnt(N) and only the oldest tile is waited for.
 // lds: W::LDS_BYTES = 2 * 64 * (P1 + P2) bytes, 16-byte aligned.
-template <class W, class RO, class LA, class LB>
-__device__ __forceinline__ void wgrad_core(int j_begin, int j_end, RO row_of, LA load_a, LB load_b,
+// fix_b(v, c) -> u32x4  : applied to a B chunk (columns [c, c+8) of the block tile) on its way from the register
+//                         slot into LDS, i.e. once the load has long landed (touching the value where it is
+//                         loaded would wait for the load there and end the pipelining)
+template <class W, class RO, class LA, class LB, class FB>
+__device__ __forceinline__ void wgrad_core(int j_begin, int j_end, RO row_of, LA load_a, LB load_b, FB fix_b,
                                            f32x4 (&acc)[W::T1][W::T2], unsigned char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w1 = wave / W::W2, w2 = wave % W::W2;
@@ -119,7 +122,7 @@ __device__ __forceinline__ void wgrad_core(int j_begin, int j_end, RO row_of, LA
 #pragma unroll
         for (int i = 0; i < W::CH2; ++i) {
             const int g = tid + i * W::NT, r = g / W::CPR2, c = g - r * W::CPR2;
-            *(u32x4*)(Bs + r * W::P2 + c * 16) = rb[sl][i];
+            *(u32x4*)(Bs + r * W::P2 + c * 16) = fix_b(rb[sl][i], c * 8);
         }
     };
     const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
@@ -170,6 +173,12 @@ __device__ __forceinline__ void wgrad_core(int j_begin, int j_end, RO row_of, LA
         step(S0{}, k);
         step(S1{}, k + 1);
     }
+}
+
+template <class W, class RO, class LA, class LB>
+__device__ __forceinline__ void wgrad_core(int j_begin, int j_end, RO row_of, LA load_a, LB load_b,
+                                           f32x4 (&acc)[W::T1][W::T2], unsigned char* lds) {
+    wgrad_core<W>(j_begin, j_end, row_of, load_a, load_b, [](u32x4 v, int) { return v; }, acc, lds);
 }
 
 // This workgroup's slice [j_begin, j_end) of a row list of `count` entries split `zs` ways in whole
@@ -542,13 +551,20 @@ __device__ __forceinline__ int gate_row(int pc, int H) {
 // d rnn.weight_ih_l0{,_reverse} [4H,E] and d linear_emb.weight [H,E]:  dWcat = DZ^T . X
 // (autograd of nn.LSTM's input GEMMs, transfer/models.py:906, and of linear_emb, :925)
 // grid: (Ncat/BN1, Ep/BN2, row splits)
+// The bias gradients ride along when E < Ep (CatBias non-NULL): they are the column sums of DZ, i.e. dWcat's
+// column for an input that is 1 in every row.  X's padding columns E..Ep-1 are zero, so the B tile that holds
+// column E gets a bf16 1.0 there on its way into LDS and the epilogue sends output column E to the biases:
+// k_colsum_dz's 63 us (cfg3) for no extra MFMA.
 // ------------------------------------------------------------------------------------------------
+struct CatBias {
+    float *bih0, *bhh0, *bih1, *bhh1, *blin;     // d rnn.bias_ih / bias_hh of both directions, d linear_emb.bias
+};
 template <class W>
 __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __restrict__ DZ,
                                                     const bf16raw* __restrict__ X,
                                                     const int* __restrict__ rows, const int* __restrict__ nrows,
                                                     float* __restrict__ gih0, float* __restrict__ gih1,
-                                                    float* __restrict__ glin) {
+                                                    float* __restrict__ glin, CatBias cb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];   // 2 * 64 * (P1 + P2) bytes
     const int n10 = blockIdx.x * W::BN1, n20 = blockIdx.y * W::BN2;
     int j_begin, j_end;
@@ -559,8 +575,14 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
         const int lo = n10, hi = min(Ncat, n10 + W::BN1) - 1;
         const bool w0 = gih0 != nullptr && lo < s.Gp, w1 = gih1 != nullptr && hi >= s.Gp && lo < 2 * s.Gp;
         const bool w2 = glin != nullptr && hi >= 2 * s.Gp;
-        if (!(w0 || w1 || w2)) return;
+        const bool b0 = (cb.bih0 != nullptr || cb.bhh0 != nullptr) && lo < s.Gp;
+        const bool b1 = (cb.bih1 != nullptr || cb.bhh1 != nullptr) && hi >= s.Gp && lo < 2 * s.Gp;
+        const bool b2 = cb.blin != nullptr && hi >= 2 * s.Gp;
+        const bool has_e = s.E < Ep && n20 <= s.E && s.E < n20 + W::BN2;      // this block's X tile holds the ones column
+        if (!(w0 || w1 || w2) && !((b0 || b1 || b2) && has_e)) return;
     }
+    const bool ones = cb.bih0 != nullptr || cb.bhh0 != nullptr || cb.bih1 != nullptr || cb.bhh1 != nullptr || cb.blin != nullptr;
+    const int ecol = ones && s.E < Ep ? s.E : -1;
     f32x4 acc[W::T1][W::T2];
     wgrad_zero<W>(acc);
     wgrad_core<W>(
@@ -573,11 +595,33 @@ __global__ __launch_bounds__(W::NT) void k_wgrad_cat(Shape s, const bf16raw* __r
             const int n = n20 + c;
             return load16_if(X + (long long)m * Ep + n, X, ok && n < Ep);
         },
+        [&](u32x4 v, int c) {
+            // the ones column (rows past the end of the list carry zeros in DZ, so they may get the 1 too)
+            const int d = ecol - (n20 + c);
+            const unsigned one = d >= 0 && d < 8 ? 0x3f80u << (16 * (d & 1)) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] |= (d >> 1) == q ? one : 0u;
+            return v;
+        },
         acc, wg_lds);
     const int E = s.E, H = s.H, Gp = s.Gp;
     wgrad_epilogue<W>(acc, [&](int r1, int r2, float v) {
         const int n1 = n10 + r1, n2 = n20 + r2;
-        if (n1 >= Ncat || n2 >= E) return;
+        if (n1 >= Ncat) return;
+        if (n2 == ecol) {                                        // column sums of DZ -> biases
+            if (n1 < 2 * Gp) {
+                const int dir = n1 >= Gp ? 1 : 0;
+                const int row = gate_row(n1 - dir * Gp, H);
+                float* bi = dir ? cb.bih1 : cb.bih0;
+                float* bh = dir ? cb.bhh1 : cb.bhh0;
+                if (row >= 0 && bi != nullptr) unsafeAtomicAdd(bi + row, v);
+                if (row >= 0 && bh != nullptr) unsafeAtomicAdd(bh + row, v);
+            } else if (n1 - 2 * Gp < H && cb.blin != nullptr) {
+                unsafeAtomicAdd(cb.blin + (n1 - 2 * Gp), v);
+            }
+            return;
+        }
+        if (n2 >= E) return;
         float* dst = nullptr;
         if (n1 < 2 * Gp) {
             const int dir = n1 >= Gp ? 1 : 0;

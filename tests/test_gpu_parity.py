@@ -451,12 +451,14 @@ def test_persistent_recurrence_matches_per_step_kernels():
     the one-launch-per-step kernels on the same inputs: hidden / cell states, dZ, outputs and dS
     agree to fp32 rounding, and repeated persistent runs are BIT-identical (a stale hand-off read
     would show as a difference), at full batch (one workgroup per CU), at a ragged batch (partial
-    sentence tile) and at H not a multiple of 64."""
+    sentence tile), at H not a multiple of 64, and at each of the three sentence-tile sizes the kernels choose
+    (lstm_fwd_tile / lstm_bwd_tile)."""
     import torch
     from sad_amd import functional as Fn, lib
     Fn.KEEP_LAST = True
     dev = torch.device("cuda:0")
-    for (B, T, V, E, H) in ((1024, 32, 500, 300, 512), (200, 17, 300, 44, 96), (64, 23, 300, 300, 512)):
+    # sentence tiles of the persistent kernels at H = 512: 128 at B = 1024, 64 at B = 300, 32 at B = 64
+    for (B, T, V, E, H) in ((1024, 32, 500, 300, 512), (200, 17, 300, 44, 96), (64, 23, 300, 300, 512), (300, 9, 300, 300, 512)):
         lengths = synth.make_lengths(B, T, seed=B)
         params = synth.make_params(V, E, H, seed=3)
         pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})

@@ -12,8 +12,10 @@ axis — e.g. the transfer loop's ``sorted_soft_out.transpose(0,1)``, reference
 transfer/models.py:1186) or ``[B,T]`` int64 ids.  The bool ``mask`` is mutated in place exactly as
 the reference mutates it (transfer/models.py:865-867).
 """
+import contextlib
 import ctypes
 
+import numpy as np
 import torch
 
 from . import lib as _lib
@@ -33,6 +35,14 @@ _RNN_PARAMS = _LIVE_PARAMS[1:9]      # the eight rnn.* tensors: all a layer abov
 
 def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_NULL_CTX = contextlib.nullcontext()
+
+
+def _on(dev):
+    """Context that makes `dev` the current device; nothing when it already is (the switch costs host time)."""
+    return _NULL_CTX if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
 
 
 def _ptr(t):
@@ -134,12 +144,15 @@ def _lengths_to_device(src_len, B, device):
     if src_len.numel() != B:
         raise RuntimeError("src_len has %d entries for a batch of %d" % (src_len.numel(), B))
     if not src_len.is_cuda:
-        ln = src_len.to(torch.int64)
+        # numpy on the tensor's own memory: the same checks as torch ops cost ~25 us of host time per call, which
+        # is what a batch-64 step through the module API waits for
+        ln = src_len.detach().contiguous().numpy()
         if B > 1 and bool((ln[1:] > ln[:-1]).any()):
             raise RuntimeError("`lengths` array must be sorted in decreasing order when `enforce_sorted` is True.")
-        if bool((ln <= 0).any()):
+        if B > 0 and int(ln.min()) <= 0:
             raise RuntimeError("Length of all samples has to be greater than 0, but found an element in "
                                "'lengths' that is <= 0")
+        return torch.from_numpy(ln.astype(np.int32, copy=False)).to(device=device, non_blocking=True)
     return src_len.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
 
 
@@ -325,7 +338,7 @@ class _Discriminator(torch.autograd.Function):
             a.onehot_stride_b, a.onehot_stride_t = oh_ids.stride(0), oh_ids.stride(1)
         if n_up:
             a.upper, a.n_upper = upper, n_up
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(_lib.load().sad_forward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf),
                                                _stream_ptr()), "sad_forward")
         ctx.set_materialize_grads(False)
@@ -393,7 +406,7 @@ class _Discriminator(torch.autograd.Function):
         if n_up:
             a.upper, a.n_upper = upper, n_up
         pgrads = [None] * len(pshapes)
-        with torch.cuda.device(dev):
+        with _on(dev):
             lib = _lib.load()
             _lib.check(lib.sad_backward(ctypes.byref(d), _ptr(pw.buf), ctypes.byref(a), _ptr(ws.buf), _stream_ptr()),
                        "sad_backward")
@@ -514,7 +527,7 @@ def _se_workspace(B, T, V, E, dev):
     ws = Workspace(d, dev)
     lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     mask = torch.zeros((B, T), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.load().sad_prep(ctypes.byref(d), _ptr(lens), _ptr(mask), mask.stride(0), mask.stride(1), 0,
                                         _ptr(ws.buf), _stream_ptr()), "sad_prep")
     if len(_se_ws) > 4:
@@ -548,7 +561,7 @@ class _SoftEmbedding(torch.autograd.Function):
         pw = _se_packed(weight)
         d, ws = _se_workspace(B, T, V, E, dev)
         kind = _lib.SRC_F32 if S.dtype == torch.float32 else _lib.SRC_BF16
-        with torch.cuda.device(dev):
+        with _on(dev):
             lib = _lib.load()
             _lib.check(lib.sad_softemb_fwd(ctypes.byref(d), _ptr(pw.buf), _ptr(Sv), kind, Sv.stride(1), Sv.stride(0),
                                            _ptr(ws.buf), _stream_ptr()), "sad_softemb_fwd")
@@ -576,7 +589,7 @@ class _SoftEmbedding(torch.autograd.Function):
         if Ep > E:
             dx[:, :, E:] = 0
         dS = dW = None
-        with torch.cuda.device(dev):
+        with _on(dev):
             lib = _lib.load()
             if ctx.needs_input_grad[0]:
                 dSv = torch.empty_strided(Sv.shape, Sv.stride(), dtype=Sv.dtype, device=dev) if _is_dense(

@@ -601,11 +601,12 @@ def test_soft_embedding_sibling_contractions():
 
 def test_ragged_and_edge_shapes():
     """Edge cases: B=1, all lengths equal to T, len==2 rows (all-masked guard), a batch and T that
-    are not multiples of any tile size, unsorted lengths given on the device (no host check)."""
+    are not multiples of any tile size, more than 256 time steps, unsorted lengths given on the device (no host check)."""
     import torch
     V, E, H = 203, 36, 40
     params = synth.make_params(V, E, H, seed=5)
-    for B, T, lens in ((1, 4, [4]), (5, 7, [7] * 5), (3, 5, [2, 2, 2]), (67, 33, None)):
+    # (T = 300: the attention kernels work through the steps in rounds of 256)
+    for B, T, lens in ((1, 4, [4]), (5, 7, [7] * 5), (3, 5, [2, 2, 2]), (67, 33, None), (3, 300, [300, 270, 2])):
         lengths = synth.make_lengths(B, T, seed=B) if lens is None else np.array(lens, np.int32)
         S = synth.make_soft_tokens(B, T, V, lengths, seed=B, kind="dense", time_major=False)
         mask = synth.transfer_mask(lengths, T)

@@ -207,10 +207,23 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     const int cpr = Hp / 8;                                  // 16-byte chunks per W row
     const int cmask = (cpr % 16 == 0) ? 15 : 3;
     {
+        // eight 16-byte loads per lane in flight (one load -> LDS store per iteration made the prologue a chain of
+        // 16 global-load latencies, ~12 us of every launch)
         const bf16raw* w = whh + ((long long)dir * Gp + n0) * Hp;
-        for (int idx = tid; idx < LF_BN * cpr; idx += 256) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            *(u32x4*)(Wl + (long long)r * Hp + lp_wswz(r, c, cmask) * 8) = *(const u32x4*)(w + (long long)r * Hp + c * 8);
+        const int total = LF_BN * cpr;
+        for (int base = 0; base < total; base += 256 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + i * 256 + tid, ic = idx < total ? idx : 0;
+                v[i] = *(const u32x4*)(w + (long long)ic * 8);            // rows are contiguous: element offset = idx * 8
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + i * 256 + tid;
+                const int r = idx / cpr, c = idx - r * cpr;
+                if (idx < total) *(u32x4*)(Wl + (long long)r * Hp + lp_wswz(r, c, cmask) * 8) = v[i];
+            }
         }
     }
     int maxlen = 0;
@@ -487,10 +500,22 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
 
     // ---- once: W_hh^T slice -> LDS; longest sentence of the tile -----------------------------------
     {
+        // eight 16-byte loads per lane in flight (see the forward kernel)
         const bf16raw* w = whhT + ((long long)dir * Hp + j0) * Gp;
-        for (int idx = tid; idx < LB_BN * cpr; idx += 512) {
-            const int r = idx / cpr, c = idx - r * cpr;
-            *(u32x4*)(Wl + (long long)r * Gp + lp_wswz(r, c, 15) * 8) = *(const u32x4*)(w + (long long)r * Gp + c * 8);
+        const int total = LB_BN * cpr;
+        for (int base = 0; base < total; base += 512 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + i * 512 + tid, ic = idx < total ? idx : 0;
+                v[i] = *(const u32x4*)(w + (long long)ic * 8);            // rows are contiguous: element offset = idx * 8
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + i * 512 + tid;
+                const int r = idx / cpr, c = idx - r * cpr;
+                if (idx < total) *(u32x4*)(Wl + (long long)r * Gp + lp_wswz(r, c, 15) * 8) = v[i];
+            }
         }
     }
     int maxlen = 0;

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the discriminator hot path: fwd+bwd sentences/s on synthetic Yelp-shaped batches.
 
-    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly
+    python bench.py [--gpus N --steps K --warmup W]            # N=1 directly; N>1: starts N rank processes itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # N>1 (driver)
+    python bench.py --gpus 2 --dry-run                         # the N-rank harness on CPU/gloo, kernels skipped
 
 One "step" = one pass of the hot path over one batch already resident in HBM: forward on soft
 tokens (K1 soft-embedding GEMM, K2 BiLSTM, K3 keys, K4 bridge, K5 attention/head/CE vs labels) +
@@ -228,9 +229,11 @@ def pmc_counters(kernel_name):
     return None, "kernel not in the counter file"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one process per GPU).  Without WORLD_SIZE in the environment and N > 1 this process "
+                         "starts the N rank processes itself; under torch.distributed.run it must equal WORLD_SIZE")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
@@ -242,90 +245,227 @@ def main():
                          "(index, value) side channel of the fused producer: K1 forward becomes a gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table (counter passes)")
-    a = ap.parse_args()
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="unfrozen mode at N > 1: one all-reduce of the whole bucket after the backward instead of two "
+                         "messages, the first beside k_wgrad_emb (dp.OverlappedGradReducer)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no kernels: process-group init (gloo), sharding for --scaling, barriers, max-over-ranks "
+                         "timing, the gradient-bucket all-reduce in the product's hook order and the rank-0 JSON line, "
+                         "with a stand-in step.  The printed value is NOT a measurement ('dry_run': true)")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, started before
+    anything in this process has touched the GPU; this parent never does) with the environment
+    torch.distributed.run would give them, wait, and return the worst exit code.  Rank 0's JSON line goes to
+    this process's stdout (inherited)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        for p_ in procs:
+            r_ = p_.wait()
+            if r_ != 0 and rc == 0:
+                rc = r_
+                for q_ in procs:                      # a dead rank leaves the others in a collective: end them
+                    if q_.poll() is None:
+                        q_.terminate()
+    except KeyboardInterrupt:
+        for q_ in procs:
+            if q_.poll() is None:
+                q_.terminate()
+        rc = 130
+    return rc
+
+
+def dry_workload(a, w, rank, world, dev):
+    """Stand-ins for --dry-run: the real lengths / shard arithmetic and a gradient bucket of the real size, but
+    no soft tokens and no kernels.  Returns (step, step_unfrozen, B_local, lengths)."""
+    from sad_amd import dp, functional as Fn, synth
+    if a.scaling == "strong":
+        lo, hi = dp.shard_bounds(w["B"], rank, world)
+        if hi - lo < 1:
+            raise SystemExit("strong scaling: fewer sentences than ranks")
+        lengths = (synth.yelp_dev_lengths if a.workload == "yelp64" else synth.make_lengths)(w["B"], w["T"], seed=1234)[lo:hi]
+    else:
+        lengths = (synth.yelp_dev_lengths if a.workload == "yelp64" else synth.make_lengths)(w["B"], w["T"], seed=1234 + rank)
+    shapes = synth.param_shapes(w["V"], w["E"], w["H"], w["L"])
+    sizes = [int(np.prod(shapes[n])) for n in Fn._LIVE_PARAMS]
+    work = torch.ones((256, 256), dtype=torch.float32, device=dev)
+
+    def step():
+        return (work @ work).sum()
+
+    reducer = None if a.no_overlap else dp.OverlappedGradReducer()
+    holders = [torch.nn.Parameter(torch.empty(n_, device=dev)) for n_ in sizes]
+
+    def step_unfrozen():
+        if reducer is not None:
+            reducer.finish()                          # what precedes the optimizer / sad_pack_weights
+        step()
+        # the backward's bucket: [embedding.weight | rest], every rank contributes rank + 1
+        flat = torch.full((sum(sizes),), float(rank + 1), dtype=torch.float32, device=dev)
+        if reducer is not None:                       # the hook order of functional._Discriminator.backward
+            reducer(flat[sizes[0]:], "rest")
+            step()                                    # stands for k_wgrad_emb running beside the first message
+            reducer(flat[:sizes[0]], "embedding")
+            reducer.finish()
+        else:
+            off = 0
+            for p_, n_ in zip(holders, sizes):
+                p_.grad = flat[off:off + n_]
+                off += n_
+            flat = dp.allreduce_grads(holders)
+        return flat
+
+    return step, step_unfrozen, len(lengths), lengths, reducer
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (a.gpus or 1) > 1:
+        # no launcher: become the launcher.  Nothing above has initialised the GPU in this process.
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:] if argv is None else argv))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus is not None and a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch as `python -m torch.distributed.run --nproc-per-node %d "
+                         "... bench.py --gpus %d`, or without a launcher as `python bench.py --gpus %d`"
+                         % (a.gpus, world, a.gpus, a.gpus, a.gpus))
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        # "nccl" == RCCL on ROCm; the dry run rehearses the same harness on gloo
+        dist.init_process_group("gloo" if a.dry_run else "nccl", rank=rank, world_size=world)
+    if a.dry_run:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
 
-    from sad_amd import dp, functional as Fn, lib, synth
-    Fn.KEEP_LAST = True                                       # the per-kernel table re-uses the step's workspace
+    def sync():
+        if not a.dry_run:
+            torch.cuda.synchronize()
+
+    from sad_amd import dp, functional as Fn, synth
     w = dict(WORKLOADS[a.workload])
     if a.s_dtype:
         w["s_dtype"] = a.s_dtype
     global_B = w["B"] * world if a.scaling == "weak" else w["B"]
-    if a.scaling == "strong":
-        lo, hi = dp.shard_bounds(w["B"], rank, world)             # contiguous slice of the SAME sorted batch
-        if hi - lo < 1:
-            raise SystemExit("strong scaling: fewer sentences than ranks")
-    params = synth.make_params(w["V"], w["E"], w["H"], w["L"], seed=21)
-    tparams = {k: torch.from_numpy(v).to(dev) for k, v in params.items()}
-    pw = Fn.pack_weights(tparams)
-    if a.scaling == "strong":
-        # every rank generates the same global batch (same seed) and keeps its shard
-        S, lengths, ln_dev, mask, labels = make_inputs(w, 1234, dev, yelp_lengths=a.workload == "yelp64")
-        S = S[:, lo:hi].contiguous()
-        lengths, ln_dev, mask, labels = lengths[lo:hi], ln_dev[lo:hi].contiguous(), mask[lo:hi].contiguous(), labels[lo:hi].contiguous()
-        w["B"] = hi - lo
+    reducer = None
+    if a.dry_run:
+        step, step_unfrozen, B, lengths, reducer = dry_workload(a, w, rank, world, dev)
+        w["B"] = B
+        T, V = w["T"], w["V"]
     else:
-        S, lengths, ln_dev, mask, labels = make_inputs(w, 1234 + rank, dev, yelp_lengths=a.workload == "yelp64")
-    B, T, V = w["B"], w["T"], w["V"]
-    onehot = None
-    if a.onehot:
-        # exact one-hot rows + their side channel, as producer.SoftTokenAssembler emits them
-        ids_tb = torch.from_numpy(synth.make_token_ids(B, T, V, lengths, seed=1234 + rank)).to(dev).t().contiguous()   # [T,B]
-        S.zero_()
-        S.scatter_(2, ids_tb.unsqueeze(2), 1.0)
-        onehot = (ids_tb.t(), torch.ones((T, B), dtype=torch.float32, device=dev).t())
-    Sv = S.transpose(0, 1).requires_grad_(True)           # [B,T,V] view, exactly like the transfer loop
+        from sad_amd import lib
+        Fn.KEEP_LAST = True                                       # the per-kernel table re-uses the step's workspace
+        if a.scaling == "strong":
+            lo, hi = dp.shard_bounds(w["B"], rank, world)             # contiguous slice of the SAME sorted batch
+            if hi - lo < 1:
+                raise SystemExit("strong scaling: fewer sentences than ranks")
+        params = synth.make_params(w["V"], w["E"], w["H"], w["L"], seed=21)
+        tparams = {k: torch.from_numpy(v).to(dev) for k, v in params.items()}
+        pw = Fn.pack_weights(tparams)
+        if a.scaling == "strong":
+            # every rank generates the same global batch (same seed) and keeps its shard
+            S, lengths, ln_dev, mask, labels = make_inputs(w, 1234, dev, yelp_lengths=a.workload == "yelp64")
+            S = S[:, lo:hi].contiguous()
+            lengths, ln_dev, mask, labels = lengths[lo:hi], ln_dev[lo:hi].contiguous(), mask[lo:hi].contiguous(), labels[lo:hi].contiguous()
+            w["B"] = hi - lo
+        else:
+            S, lengths, ln_dev, mask, labels = make_inputs(w, 1234 + rank, dev, yelp_lengths=a.workload == "yelp64")
+        B, T, V = w["B"], w["T"], w["V"]
+        onehot = None
+        if a.onehot:
+            # exact one-hot rows + their side channel, as producer.SoftTokenAssembler emits them
+            ids_tb = torch.from_numpy(synth.make_token_ids(B, T, V, lengths, seed=1234 + rank)).to(dev).t().contiguous()   # [T,B]
+            S.zero_()
+            S.scatter_(2, ids_tb.unsqueeze(2), 1.0)
+            onehot = (ids_tb.t(), torch.ones((T, B), dtype=torch.float32, device=dev).t())
+        Sv = S.transpose(0, 1).requires_grad_(True)           # [B,T,V] view, exactly like the transfer loop
 
-    if a.api == "module":
-        # the drop-in module as reference transfer/models.py:1172-1212 drives it: CPU int16 lengths,
-        # bool mask, soft=True, un-fused CE against the inverted label
-        from types import SimpleNamespace
-        from sad_amd import transfer_models
-        cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0, enc_num_layers=1,
-                              hidden_size=w["H"], vocab_size=V, emb_size=w["E"], num_labels=w["L"],
-                              freeze_embedding=False, device=str(dev), mask_id=None)
-        model = transfer_models.SelfAttnRNNClassifier(cfg)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
-        model.to(dev)
-        for p_ in model.parameters():                     # TransferModel.freeze_cls (transfer/models.py:995-999)
-            p_.requires_grad = False
-        len16 = torch.from_numpy(lengths.astype(np.int16))
-        inv_lab = 1 - labels
+        if a.api == "module":
+            # the drop-in module as reference transfer/models.py:1172-1212 drives it: CPU int16 lengths,
+            # bool mask, soft=True, un-fused CE against the inverted label
+            from types import SimpleNamespace
+            from sad_amd import transfer_models
+            cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0, enc_num_layers=1,
+                                  hidden_size=w["H"], vocab_size=V, emb_size=w["E"], num_labels=w["L"],
+                                  freeze_embedding=False, device=str(dev), mask_id=None)
+            model = transfer_models.SelfAttnRNNClassifier(cfg)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+            model.to(dev)
+            for p_ in model.parameters():                     # TransferModel.freeze_cls (transfer/models.py:995-999)
+                p_.requires_grad = False
+            len16 = torch.from_numpy(lengths.astype(np.int16))
+            inv_lab = 1 - labels
 
-        def step():
+            def step():
+                Sv.grad = None
+                logits, _ = model(Sv, len16, mask.clone(), soft=True, onehot=onehot)
+                loss = torch.nn.functional.cross_entropy(logits, inv_lab, reduction="none")
+                (loss.sum() / global_B).backward()
+                return loss
+        else:
+            def step():
+                Sv.grad = None
+                loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, onehot=onehot)
+                (loss.sum() / global_B).backward()
+                return loss
+
+        # --- unfrozen mode (SURVEY.md §8 d1): + parameter gradients, + the all-reduce of the flat grad bucket
+        # over RCCL when N > 1, + re-packing the weights (an optimizer step invalidates the image).  At N > 1
+        # the bucket travels in two messages (dp.OverlappedGradReducer): everything but embedding.weight is
+        # handed to RCCL while k_wgrad_emb (the longest weight-gradient kernel) still runs, embedding.weight
+        # after it; both are waited for before the next sad_pack_weights, so no collective kernel is in flight
+        # when the persistent recurrences (which need every CU) start.  DESIGN.md "Multi-GPU".
+        live = {k: tparams[k].clone().requires_grad_(True) for k in Fn._LIVE_PARAMS}
+        if world > 1 and not a.no_overlap:
+            reducer = dp.OverlappedGradReducer()
+
+        def step_unfrozen():
             Sv.grad = None
-            logits, _ = model(Sv, len16, mask.clone(), soft=True, onehot=onehot)
-            loss = torch.nn.functional.cross_entropy(logits, inv_lab, reduction="none")
-            (loss.sum() / global_B).backward()
-            return loss
-    else:
-        def step():
-            Sv.grad = None
-            loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, onehot=onehot)
-            (loss.sum() / global_B).backward()
-            return loss
+            for p_ in live.values():
+                p_.grad = None
+            if reducer is not None:
+                reducer.finish()                              # the previous step's messages, before the re-pack
+            pw.pack(live)
+            loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, params=live, pad_id=0)
+            Fn.GRAD_READY_HOOK = reducer
+            try:
+                (loss.sum() / global_B).backward()
+            finally:
+                Fn.GRAD_READY_HOOK = None
+            if reducer is not None:
+                reducer.finish()
+                return Fn._Discriminator.last_grad_bucket
+            return dp.allreduce_grads(list(live.values()))       # the grads are views of ONE bucket: reduced in place
 
     def timed(fn, steps, warm):
         for _ in range(warm):
             fn()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         el = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -334,37 +474,32 @@ def main():
         return el
 
     el = timed(step, a.steps, a.warmup)
-
-    # --- unfrozen mode: + parameter gradients, + one all-reduce of the flat grad
-    # bucket over RCCL when N > 1, + re-packing the weights (an optimizer step invalidates the image).
-    # The all-reduce runs after the backward on the same stream: the persistent recurrences need the
-    # whole device (co-residency), so it is not overlapped with the BPTT (DESIGN.md "Multi-GPU").
-    live = {k: tparams[k].clone().requires_grad_(True) for k in Fn._LIVE_PARAMS}
-
-    def step_unfrozen():
-        Sv.grad = None
-        for p_ in live.values():
-            p_.grad = None
-        pw.pack(live)
-        loss, _, _ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw, params=live, pad_id=0)
-        (loss.sum() / global_B).backward()
-        return dp.allreduce_grads(list(live.values()))       # the grads are views of ONE bucket: reduced in place
-
     u_steps = max(1, min(a.steps, 10))
     el_u = timed(step_unfrozen, u_steps, 2)
     bucket = step_unfrozen()
-    pw.pack(tparams)
-    # leave a frozen step's workspace behind for the per-kernel timing below
-    Sv.grad = None
-    loss_, logits_, weights_ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
-    (loss_.sum() / global_B).backward()
-    torch.cuda.synchronize()
-    ws = Fn._Discriminator.last_workspace
-    ws.check()                                               # hand-off timeout words of the recurrences
+    kernels, roofline, cpu, extra = None, None, None, {}
+    if a.dry_run:
+        # every rank filled its bucket with rank + 1: the reduced bucket must hold 1 + 2 + ... + world everywhere
+        want = world * (world + 1) / 2.0
+        ok = bool((bucket == want).all())
+        extra = {"dry_run": True, "note": "harness rehearsal on CPU/gloo with a stand-in step: NOT a measurement",
+                 "bucket_allreduce_ok": ok, "bucket_numel": int(bucket.numel()),
+                 "messages_per_step": [list(x) for x in (reducer.log[-2:] if reducer is not None else [("all", int(bucket.numel()))])],
+                 "local_batch": B, "backend": "gloo" if world > 1 else None}
+        if not ok:
+            raise SystemExit("dry run: the all-reduced gradient bucket is wrong on rank %d" % rank)
+    else:
+        pw.pack(tparams)
+        # leave a frozen step's workspace behind for the per-kernel timing below
+        Sv.grad = None
+        loss_, logits_, weights_ = Fn.discriminator_loss(Sv, ln_dev, mask, labels, pw)
+        (loss_.sum() / global_B).backward()
+        torch.cuda.synchronize()
+        ws = Fn._Discriminator.last_workspace
+        ws.check()                                               # hand-off timeout words of the recurrences
 
     if rank == 0:
-        kernels, roofline = None, None
-        if not a.no_kernels:
+        if not a.dry_run and not a.no_kernels:
             kernels = kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits_.detach(), weights_.detach())
             dom = max(kernels, key=lambda e: e["avg_launch_us"])
             if dom["bound"] == "hbm" or (dom["bound"] == "mfma+hbm" and dom.get("hbm_frac", 0) >= dom.get("mfma_frac", 0)):
@@ -383,8 +518,7 @@ def main():
                 roofline["traffic_note"] = why or "counters are taken on the default workload only"
             elif "mfma_busy_frac" in cnt:
                 roofline["mfma_busy_frac_pmc"] = cnt["mfma_busy_frac"]
-        cpu = None
-        if world == 1 and not a.no_cpu_baseline:
+        if not a.dry_run and world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(w, params, S, lengths, mask, labels)
         units = (B * world if a.scaling == "weak" else global_B)
         out = {
@@ -392,7 +526,10 @@ def main():
             "value": round(units * a.steps / el, 1), "unit": "sentences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": a.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None,
+            # the arithmetic type of the contractions; fp32 soft tokens are rounded to bf16 on their way into the MFMAs
+            "dtype": "bf16" if w["s_dtype"] == "bf16" else "bf16 (fp32 soft tokens / d(soft tokens) in HBM)",
+            "data": "synthetic",
             "config": {"workload": "%s: synthetic Yelp-shaped soft tokens, B=%d per GPU, T=%d, V=%d, E=%d, H=%d, "
                                    "len %s sorted, S %s%s, frozen discriminator (no param grads, no collective), api=%s"
                                    % (a.workload, B, T, V, w["E"], w["H"],
@@ -406,10 +543,15 @@ def main():
             "unfrozen": {"value": round(units * u_steps / el_u, 1), "unit": "sentences/s", "steps": u_steps,
                          "ms_per_step": round(el_u / u_steps * 1e3, 4),
                          "what": "same batch, + all 19 parameter gradients + weight re-pack"
-                                 + (" + all-reduce of the %.1f MB fp32 grad bucket (RCCL)" % (bucket.numel() * 4 / 1e6)
-                                    if world > 1 else "")},
-            "source_id": source_id(), "sad_version": lib.load().sad_version(),
+                                 + ((" + all-reduce of the %.1f MB fp32 grad bucket (%s), %s"
+                                     % (bucket.numel() * 4 / 1e6, "gloo" if a.dry_run else "RCCL",
+                                        "one message after the backward" if reducer is None else
+                                        "two messages, the first beside k_wgrad_emb")) if world > 1 else "")},
+            "source_id": source_id(),
         }
+        if not a.dry_run:
+            out["sad_version"] = lib.load().sad_version()
+        out.update(extra)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

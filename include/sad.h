@@ -12,7 +12,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
  *     asynchronously on it, nothing here synchronises or allocates;
  *   - functions return 0 on success, <0 on error; `sad_last_error()` (thread-local, host string)
- *     describes the last failure of the calling thread;
+ *     describes the last failure of the calling thread (-1 bad argument, -2 HIP error, -3 shape beyond
+ *     sad_forward_noalloc's static scratch, -4 an EARLIER call's persistent recurrence timed out: see sad_forward);
  *   - token rows are addressed through explicit element strides, so both the transfer loop's
  *     time-major soft tokens ([T,B,V] storage viewed as [B,T,V]) and batch-major tensors work
  *     without copies; the vocabulary axis must be contiguous.
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAD_VERSION 211 /* 0.2.1 */
+#define SAD_VERSION 300 /* 0.3.0 */
 
 /* src_kind / dsrc_kind */
 #define SAD_SRC_IDS 0  /* int64 token ids [B,T]                  (reference: self.embedding(src)) */
@@ -225,7 +226,12 @@ int sad_pack_weights(const sad_dims* d, const sad_weights* w, void* packed, void
 /* SelfAttnRNNClassifier.forward (reference transfer/models.py:885-953 incl. attention :841-883;
  * classifier copy classifier/models.py:200-266 with guard = 0) + per-sentence
  * nn.CrossEntropyLoss(reduction='none') (transfer/models.py:990,1212) when labels/loss are given.
- * Saves what the backward needs in `workspace`. */
+ * Saves what the backward needs in `workspace`.
+ * Returns -4 (and starts nothing) when a hand-off wait inside a persistent recurrence of an EARLIER call on the
+ * current device timed out: that call's outputs are NaN by construction, the recurrence raised a word of
+ * host-mapped memory (created by the first sad_pack_weights on the device) and this call reports and clears it --
+ * no synchronisation involved; the call after it runs normally.  (The reference has no counterpart: its callers
+ * catch RuntimeError around the step, classifier/trainers.py:375-382.) */
 int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, void* workspace, void* stream);
 
 /* sad_forward without a workspace argument and without any allocation.  It has NO counterpart in the
@@ -348,6 +354,7 @@ int sad_soft_finalize(int32_t B, int32_t T, int32_t V, int32_t steps, int32_t ov
 #define SAD_DBG_SPIN_LIMIT 1
 #define SAD_DBG_WITHHOLD_FWD 2
 #define SAD_DBG_WITHHOLD_BWD 3
+#define SAD_DBG_WITHHOLD_UPPER_ONLY 4 /* 1: the two settings above act only on RNN layers above the first */
 int sad_debug_set(int32_t key, int64_t value);
 
 #ifdef __cplusplus

@@ -109,14 +109,17 @@ __device__ __forceinline__ int lp_wswz(int col, int chunk, int cmask) { return c
 // workgroup's LDS flag `dead` is set: from then on the workgroup stops waiting and publishes NaN
 // instead of results computed from stale hand-off data, so the failure reaches logits / loss / dS
 // (a NaN h or dZ propagates through every later product) instead of passing silently.
+// `hostflag` (or NULL): a word of host-mapped memory the library owns per device; raised too, so that the NEXT
+// sad_forward on the device can refuse with the reason without anybody synchronising (sad_api.hip).
 __device__ __forceinline__ void lp_wait(gu32* counter, unsigned target, unsigned spin_limit, gu32* errword,
-                                        volatile unsigned* dead) {
+                                        volatile unsigned* dead, unsigned* hostflag, unsigned code) {
     if (*dead) return;
     unsigned spins = 0;
     while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > spin_limit) {
             __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
+            if (hostflag != nullptr) __hip_atomic_store(hostflag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             *dead = 1u;
             break;
         }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
                                                           unsigned short* __restrict__ GA, unsigned* sync,
-                                                          unsigned spin_limit, int withhold, int bm) {
+                                                          unsigned spin_limit, int withhold, int bm, unsigned* hostflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
     bf16raw* Wl = (bf16raw*)lp_lds;                          // [64][Hp], chunk-swizzled
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
         LF_PROF_T(0)
         if (done > 0) {
-            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead);
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 1u);
             LF_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
             __syncthreads();
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
                                                          bf16raw* DZ, bf16raw* DZX, const unsigned short* __restrict__ GA, unsigned* sync,
                                                          unsigned spin_limit, int withhold,
-                                                         const bf16raw* __restrict__ DHS, int ldh, int bm) {
+                                                         const bf16raw* __restrict__ DHS, int ldh, int bm, unsigned* hostflag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T, Ncat = s.Ncat;
     LB_PROF_ENTRY
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         LB_PROF_T(0)
         if (done > 0) {
-            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead);
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 2u);
             LB_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();

@@ -55,11 +55,14 @@ __device__ __forceinline__ float load_soft(const void* row, long long v) {
 template <int KIND>
 __global__ __launch_bounds__(256) void k_gumbel_st_fwd(int B, int V, const float* __restrict__ logits, long long ldl,
                                                       const float* __restrict__ noise, long long ldn, float tau,
-                                                      const unsigned char* __restrict__ alive, int eos_id,
+                                                      const unsigned char* alive, int eos_id,
                                                       void* __restrict__ S_row, long long ldS, float* __restrict__ rnn_in,
                                                       float* __restrict__ y_soft, long long* __restrict__ idx_out,
                                                       float* __restrict__ val_out, int* __restrict__ lens,
-                                                      unsigned char* __restrict__ alive_out) {
+                                                      unsigned char* alive_out) {
+    // `alive_out` may be the same buffer as `alive` (no __restrict__ on either): every thread reads its sentence's
+    // byte here, in front of the first barrier, and thread 0 writes the new one behind the last.
+    const bool live = alive == nullptr || alive[blockIdx.x] != 0;
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     __shared__ float red_s[4];
@@ -85,7 +88,6 @@ __global__ __launch_bounds__(256) void k_gumbel_st_fwd(int B, int V, const float
     if (lane == 0) red_s[wave] = part;
     __syncthreads();
     const float sum = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
-    const bool live = alive == nullptr || alive[b] != 0;
     const float y_idx = expf((lg[idx] + nz[idx]) / tau - zmax) / sum;
     const float val = (1.0f - y_idx) + y_idx;      // y_hard - y_soft + y_soft at the arg-max; exactly 0 elsewhere
     void* srow = (char*)S_row + (long long)b * ldS * (KIND == SRC_F32 ? 4 : 2);

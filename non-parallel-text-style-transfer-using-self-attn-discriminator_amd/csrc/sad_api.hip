@@ -45,6 +45,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 std::atomic<int> g_no_persist{-1};                       // -1: not set -> SAD_NO_PERSIST of the environment, read once
 std::atomic<unsigned> g_spin_limit{LP_SPIN_LIMIT};       // bound of a hand-off wait inside the persistent recurrences
 std::atomic<int> g_withhold_fwd{-1}, g_withhold_bwd{-1}; // workgroup that exits at once (forces a hand-off timeout)
+std::atomic<int> g_withhold_upper_only{0};               // 1: only in the launches of RNN layers above the first
 
 bool no_persist() {
     int v = g_no_persist.load(std::memory_order_relaxed);
@@ -68,9 +69,9 @@ struct KernelFacts {
     int threads;
     int per_cu;                                          // co-resident workgroups per CU at (threads, lds); -1 = query failed
 };
-constexpr int MAX_KERNEL_FACTS = 64;
-KernelFacts g_facts[MAX_KERNEL_FACTS];
-int g_nfacts = 0;
+constexpr int MAX_KERNEL_FACTS = 48;                     // per device; a full table evicts its oldest entry
+KernelFacts g_facts[MAX_DEVICES][MAX_KERNEL_FACTS];
+int g_nfacts[MAX_DEVICES], g_fact_next[MAX_DEVICES];
 
 int current_device() {
     int dev = 0;
@@ -92,19 +93,60 @@ int device_cus() {
 int kernel_per_cu(const void* kernel, size_t lds, int threads) {
     const int dev = current_device();
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    for (int i = 0; i < g_nfacts; ++i)
-        if (g_facts[i].dev == dev && g_facts[i].kernel == kernel && g_facts[i].lds == lds && g_facts[i].threads == threads)
-            return g_facts[i].per_cu;
+    KernelFacts* facts = g_facts[dev];
+    for (int i = 0; i < g_nfacts[dev]; ++i)
+        if (facts[i].kernel == kernel && facts[i].lds == lds && facts[i].threads == threads) return facts[i].per_cu;
     int per_cu = -1;
     if (lds <= 65536 || hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) per_cu = -1;
     }
     (void)hipGetLastError();
-    if (g_nfacts < MAX_KERNEL_FACTS) g_facts[g_nfacts++] = KernelFacts{dev, kernel, lds, threads, per_cu};
+    if (g_nfacts[dev] < MAX_KERNEL_FACTS) {
+        facts[g_nfacts[dev]++] = KernelFacts{dev, kernel, lds, threads, per_cu};
+    } else {
+        facts[g_fact_next[dev]] = KernelFacts{dev, kernel, lds, threads, per_cu};
+        g_fact_next[dev] = (g_fact_next[dev] + 1) % MAX_KERNEL_FACTS;
+    }
     return per_cu;
 }
 // Kernels with more than 64 KB of dynamic LDS: the limit has to be raised once per device.
 void allow_lds(const void* kernel, size_t lds, int threads) { (void)kernel_per_cu(kernel, lds, threads); }
+
+// ---- hand-off time-outs surfaced without a synchronisation ------------------------------------------
+// One word of host-mapped (pinned) memory per device, created by the first sad_pack_weights on that device (the
+// library's set-up call; the compute entry points never allocate).  A persistent recurrence whose hand-off wait
+// times out raises it from the device (system-scope store: 1 = forward recurrence, 2 = BPTT) besides poisoning
+// its outputs with NaN; the next sad_forward on the device reads it with a plain host load, refuses (-4) with the
+// reason and clears it.  Without it a time-out in production is a NaN loss whose reason only Workspace.check()
+// (a synchronising read of the workspace) could tell.
+unsigned* g_hostflag[MAX_DEVICES];        // host address
+unsigned* g_hostflag_dev[MAX_DEVICES];    // the same word as the device sees it
+void ensure_hostflag() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (g_hostflag[dev] != nullptr) return;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || h == nullptr) { (void)hipGetLastError(); return; }
+    memset(h, 0, 64);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || d == nullptr) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+    g_hostflag_dev[dev] = (unsigned*)d;
+    g_hostflag[dev] = (unsigned*)h;
+}
+unsigned* hostflag_dev() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    return g_hostflag[dev] != nullptr ? g_hostflag_dev[dev] : nullptr;
+}
+// returns the raised code (and clears it), 0 if none
+unsigned take_hostflag() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    volatile unsigned* f = g_hostflag[dev];
+    if (f == nullptr) return 0;
+    const unsigned v = *f;
+    if (v != 0) *f = 0;
+    return v;
+}
 
 struct PackedLayout {
     size_t wembT, wemb, wcat, wcatT, bcat, whh, whhT, whb0, whb0T, bhb0, wq, wqT, bq, wa, ba, wo, bo, total;
@@ -491,6 +533,7 @@ int sad_pack_weights(const sad_dims* d, const sad_weights* w, void* packed, void
     for (size_t i = 0; i < sizeof(need) / sizeof(need[0]); ++i)
         if (need[i] == nullptr) return fail(-1, "sad_weights field #%zu is NULL", i);
     hipStream_t st = (hipStream_t)stream;
+    ensure_hostflag();                                       // set-up call: the time-out word of this device
     const PackedLayout p = packed_layout(s);
     const IdxMap idE{MAP_ID, s.E, s.H, s.Hp}, idV{MAP_ID, s.V, s.H, s.Hp}, idH{MAP_ID, s.H, s.H, s.Hp};
     const IdxMap idL{MAP_ID, s.L, s.H, s.Hp}, id1{MAP_ID, 1, s.H, s.Hp};
@@ -579,6 +622,7 @@ struct Ctx {
     const void* packed;
     void* ws;
     hipStream_t st;
+    bool upper = false;                                      // an RNN layer above the first (sad_rnn_layer)
 };
 
 // K2a + K3: [G | Kk] = X . Wcat^T + bcat
@@ -625,7 +669,8 @@ int run_lstm_fwd(const Ctx& c) {
                            Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
-                           g_withhold_fwd.load(std::memory_order_relaxed), lstm_fwd_bm(s));
+                           (c.upper || !g_withhold_upper_only.load(std::memory_order_relaxed)) ? g_withhold_fwd.load(std::memory_order_relaxed) : -1,
+                           lstm_fwd_bm(s), hostflag_dev());
     } else {
         for (int step = 0; step < s.T; ++step) {
             if (s.B >= 512) {
@@ -753,7 +798,9 @@ int run_lstm_bwd(const Ctx& c, const bf16raw* dhs = nullptr, int ldh = 0) {
                            Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
-                           g_withhold_bwd.load(std::memory_order_relaxed), dhs, ldh, lstm_bwd_tile(s.B, s.Hp, device_cus()));
+                           (c.upper || !g_withhold_upper_only.load(std::memory_order_relaxed)) ? g_withhold_bwd.load(std::memory_order_relaxed) : -1,
+                           dhs, ldh, lstm_bwd_tile(s.B, s.Hp, device_cus()),
+                           hostflag_dev());
     } else {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;
@@ -864,6 +911,7 @@ int make_upper_ctx(const Ctx& c0, const sad_rnn_layer* upper, int n_upper, int i
     if (upper == nullptr) return fail(-1, "n_upper=%d but upper is NULL", n_upper);
     sad_dims du = {c0.s.B, c0.s.T, 1, 2 * c0.s.H, c0.s.H, c0.s.L, c0.s.cell};
     if (make_ctx(&du, upper[i].packed, upper[i].workspace, (void*)c0.st, cu)) return -1;
+    cu->upper = true;
     return 0;
 }
 
@@ -892,10 +940,22 @@ int run_upper_fwd(const Ctx& c0, const sad_fwd_args* a) {
     return run_bridge_fwd(c0, *below);
 }
 
+int check_upper(const sad_rnn_layer* upper, int n_upper) {
+    if (n_upper < 0 || n_upper > SAD_MAX_UPPER_LAYERS) return fail(-1, "n_upper=%d outside 0..%d", n_upper, SAD_MAX_UPPER_LAYERS);
+    if (n_upper > 0 && upper == nullptr) return fail(-1, "n_upper=%d but upper is NULL", n_upper);
+    return 0;
+}
+
 int forward_impl(const Ctx& c_in, const sad_fwd_args* a) {
     if (check_ptr(a, "args")) return -1;
+    if (check_upper(a->upper, a->n_upper)) return -1;
     const Ctx& c = c_in;
     const Shape& s = c.s;
+    if (const unsigned code = take_hostflag())
+        return fail(-4, "a hand-off wait inside the persistent %s of an EARLIER call on this device timed out (its workgroups "
+                        "were not co-resident: another kernel on the device?); logits / loss / d(soft tokens) of that call "
+                        "are NaN.  This call was not started; the next one will be",
+                    code == 2 ? "BPTT" : "forward recurrence");
     if (check_ptr(a->src, "src") || check_ptr(a->lengths, "lengths") || check_ptr(a->mask, "mask") ||
         check_ptr(a->logits, "logits") || check_ptr(a->weights, "weights"))
         return -1;
@@ -957,7 +1017,7 @@ int sad_forward(const sad_dims* d, const void* packed, const sad_fwd_args* a, vo
 int sad_backward(const sad_dims* d, const void* packed, const sad_bwd_args* a, void* ws, void* stream) {
     Ctx c;
     if (make_ctx(d, packed, ws, stream, &c)) return -1;
-    if (check_bwd_args(a)) return -1;
+    if (check_bwd_args(a) || check_upper(a->upper, a->n_upper)) return -1;
     int rc;
     if ((rc = run_attn_bwd(c, a)) != 0) return rc;
     if (a->n_upper == 0) {
@@ -1126,6 +1186,7 @@ int sad_debug_set(int32_t key, int64_t value) {
         case SAD_DBG_SPIN_LIMIT: g_spin_limit.store(value <= 0 ? LP_SPIN_LIMIT : (unsigned)value); return 0;
         case SAD_DBG_WITHHOLD_FWD: g_withhold_fwd.store((int)value); return 0;
         case SAD_DBG_WITHHOLD_BWD: g_withhold_bwd.store((int)value); return 0;
+        case SAD_DBG_WITHHOLD_UPPER_ONLY: g_withhold_upper_only.store(value != 0 ? 1 : 0); return 0;
         default: return fail(-1, "unknown debug key %d", key);
     }
 }
@@ -1263,8 +1324,10 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         }
         SAD_CHECK_LAUNCH("k_wgrad_dense");
     }
-    // small reductions over sentences: one launch (short serial sums: the kernel is a latency chain)
-    {
+    // small reductions over sentences: one launch (short serial sums: the kernel is a latency chain); skipped when
+    // none of its six outputs is wanted (e.g. the embedding-only stage of a data-parallel backward)
+    if (g->hidden_bridge0_bias != nullptr || g->linear_q_bias != nullptr || g->linear_attn_weight != nullptr ||
+        g->linear_attn_bias != nullptr || g->output_layer_bias != nullptr || g->output_layer_weight != nullptr) {
         ColsumJobs jobs;
         const float* srcs[5] = {DQ, DU, DWA, DSSUM, DL};
         float* dsts[5] = {g->hidden_bridge0_bias, g->linear_q_bias, g->linear_attn_weight, g->linear_attn_bias, g->output_layer_bias};

@@ -83,3 +83,48 @@ def allreduce_grads(params, bucket=None):
         g.copy_(bucket[o:o + g.numel()].view_as(g))
         o += g.numel()
     return bucket
+
+
+class OverlappedGradReducer:
+    """Sum-all-reduce of the discriminator's gradient bucket in TWO messages, the first one issued while
+    the backward is still running ("launch on a side stream as soon as BPTT finishes the
+    LSTM wgrads, embedding wgrad (11.2 MB) last").
+
+    ``functional._Discriminator.backward`` writes the parameter gradients in two stages into one flat
+    bucket ``[embedding.weight | everything else]``: first every tensor but ``embedding.weight``
+    (`k_wgrad_cat`, `k_wgrad_hh`, the dense layers and the small reductions), then
+    ``embedding.weight`` (`k_wgrad_emb`, the longest weight-gradient kernel).  With this object
+    installed as ``functional.GRAD_READY_HOOK`` the first span is handed to the collective as soon as
+    its kernels are enqueued: ``dist.all_reduce(..., async_op=True)`` runs on the process group's own
+    stream (RCCL) behind an event of the compute stream, i.e. beside `k_wgrad_emb`, which is an
+    ordinary (non-persistent) launch.  The persistent recurrences need every CU (co-residency), so
+    nothing may still be in flight when the next forward starts: call :meth:`finish` before the
+    optimizer step / the next ``sad_pack_weights`` — it makes the compute stream wait for both
+    messages.
+
+    Stream / event order per step (what ``bench.py --dry-run`` and tests/test_bench_dryrun.py replay on
+    gloo):  backward kernels -> hook("rest") -> k_wgrad_emb -> hook("embedding") -> finish() ->
+    optimizer -> sad_pack_weights -> next forward.
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.pending = []
+        self.log = []          # (tag, numel) per issued message, for tests
+
+    def _multi(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def __call__(self, span, tag):
+        """The hook: `span` is a contiguous fp32 view of the bucket whose kernels have been enqueued."""
+        self.log.append((tag, int(span.numel())))
+        if span.numel() and self._multi():
+            self.pending.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Make the current stream wait for every message issued since the last call."""
+        for w in self.pending:
+            w.wait()
+        n = len(self.pending)
+        self.pending = []
+        return n

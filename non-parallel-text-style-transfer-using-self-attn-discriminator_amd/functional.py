@@ -165,6 +165,7 @@ class Workspace:
             raise RuntimeError("libsad sad_workspace_bytes failed: " + _lib.last_error())
         self.d = d
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.upper = []      # workspaces of the RNN layers above the first (each runs its own recurrences)
 
     def view(self, name, dtype):
         off, nb = _lib.workspace_field(self.d, name)
@@ -173,8 +174,11 @@ class Workspace:
     def handoff_timeouts(self):
         """(forward, backward) timeout words of the persistent recurrences.  SYNCHRONISES (reads device
         memory): call it where a sync happens anyway (tests, benchmarks, a logging interval)."""
-        words = self.view("SYNC", torch.int32)[-32:-30].tolist()
-        return int(words[0]), int(words[1])
+        f = b = 0
+        for w in [self] + list(self.upper):          # a multi-layer model: any layer's recurrences
+            words = w.view("SYNC", torch.int32)[-32:-30].tolist()
+            f, b = f | int(words[0]), b | int(words[1])
+        return f, b
 
     def check(self):
         """Raise RuntimeError if a hand-off wait inside a persistent recurrence timed out during the
@@ -246,6 +250,22 @@ def _grad_struct(views):
 
 _N_FIXED = 10   # forward() arguments in front of *params
 
+# Data-parallel hook: callable(span, tag) or None.  When set, the backward calls it with contiguous fp32
+# spans of the flat gradient bucket as soon as the kernels that fill them are enqueued on the current
+# stream ("rest" = every live tensor but embedding.weight, then "embedding"; "all" when embedding.weight
+# is frozen) -- see dp.OverlappedGradReducer.
+GRAD_READY_HOOK = None
+
+
+def _upper_grads(lib, d_up, ws_up, views, n_up):
+    """Parameter gradients of the RNN layers above the first (their own dims / workspaces)."""
+    for i in range(n_up):
+        pre = "upper%d." % i
+        gu = _grad_struct({n: views[pre + n] for n in _RNN_PARAMS if pre + n in views})
+        _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d_up), ctypes.byref(gu), None, _lib.SRC_IDS, 0, 0,
+                                                  -1, _ptr(ws_up[i].buf), _stream_ptr()),
+                   "sad_param_grads_accumulate(upper layer)")
+
 # Debug / profiling hook (tests, bench.py, tools): when True the last call's Workspace and flat
 # gradient bucket stay reachable as _Discriminator.last_workspace / .last_grad_bucket.  Off by
 # default: the hook would keep one full workspace alive for the life of the process.
@@ -293,6 +313,7 @@ class _Discriminator(torch.autograd.Function):
         # RNN layers above the first: own dims / image / workspace each (include/sad.h, sad_rnn_layer)
         d_up = _lib.dims(B, T, 1, 2 * pw.H, pw.H, pw.L, pw.cell)
         ws_up = [Workspace(d_up, dev) for _ in range(n_up)]
+        ws.upper = ws_up
         upper = (_lib.SadRnnLayer * max(n_up, 1))()
         keeps_up = []
         for i in range(n_up):
@@ -422,19 +443,30 @@ class _Discriminator(torch.autograd.Function):
                         pgrads[i] = flat[off:off + sizes[i]].view(s)
                         views[name] = pgrads[i]
                         off += sizes[i]
-                g = _grad_struct(views)
-                if n_up:
-                    g.final_hidden_workspace = ws_up[-1].buf.data_ptr()
                 sp = src.data_ptr() if src is not None else None
                 sb, st_ = (strides[0], strides[1])
-                _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d), ctypes.byref(g), sp, kind, sb, st_, pad_id,
-                                                          _ptr(ws.buf), _stream_ptr()), "sad_param_grads_accumulate")
-                for i in range(n_up):
-                    pre = "upper%d." % i
-                    gu = _grad_struct({n: views[pre + n] for n in _RNN_PARAMS if pre + n in views})
-                    _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d_up), ctypes.byref(gu), None, _lib.SRC_IDS, 0, 0,
-                                                              -1, _ptr(ws_up[i].buf), _stream_ptr()),
-                               "sad_param_grads_accumulate(upper layer)")
+                hook = GRAD_READY_HOOK
+                # With a hook (data-parallel training, dp.OverlappedGradReducer) the gradients are written in two
+                # stages -- everything but embedding.weight, then embedding.weight (the longest kernel, first in
+                # the bucket) -- and each span is handed to the hook as soon as its kernels are enqueued, so the
+                # first all-reduce message travels beside k_wgrad_emb.
+                stages = [views] if hook is None or "embedding.weight" not in views else [
+                    {k: v for k, v in views.items() if k != "embedding.weight"}, {"embedding.weight": views["embedding.weight"]}]
+                for si, stage in enumerate(stages):
+                    g = _grad_struct(stage)
+                    if n_up:
+                        g.final_hidden_workspace = ws_up[-1].buf.data_ptr()
+                    _lib.check(lib.sad_param_grads_accumulate(ctypes.byref(d), ctypes.byref(g), sp, kind, sb, st_, pad_id,
+                                                              _ptr(ws.buf), _stream_ptr()), "sad_param_grads_accumulate")
+                    if si == 0 and len(stages) == 2:
+                        _upper_grads(lib, d_up, ws_up, views, n_up)
+                        hook(flat[sizes[0]:], "rest")
+                if len(stages) == 2:
+                    hook(flat[:sizes[0]], "embedding")
+                else:
+                    _upper_grads(lib, d_up, ws_up, views, n_up)
+                    if hook is not None:
+                        hook(flat, "all")
                 if KEEP_LAST:
                     _Discriminator.last_grad_bucket = flat
         del keep

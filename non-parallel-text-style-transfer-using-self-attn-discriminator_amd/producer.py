@@ -43,19 +43,41 @@ def gumbel_noise_like(logits):
     return -torch.empty_like(logits, memory_format=torch.legacy_contiguous_format).exponential_().log()
 
 
+def _step_backward(meta, y_soft, alive, d_s_row, g_rnn):
+    """dlogits of one decode step (sad_gumbel_st_step_bwd).  `meta` = (B, V, kind, dtype, tau, device): plain
+    values, so that no autograd context has to keep the assembler alive."""
+    B, V, kind, dtype, tau, device = meta
+    dl = torch.empty((B, V), dtype=torch.float32, device=device)
+    if d_s_row is not None and (d_s_row.stride(1) != 1 or d_s_row.dtype != dtype):
+        d_s_row = d_s_row.to(dtype).contiguous()
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().sad_gumbel_st_step_bwd(
+            B, V, _ptr(d_s_row), kind, d_s_row.stride(0) if d_s_row is not None else 0, _ptr(g_rnn),
+            _ptr(alive), _ptr(y_soft), tau, _ptr(dl), dl.stride(0), _stream()), "sad_gumbel_st_step_bwd")
+    return dl
+
+
+# Neither autograd function keeps the assembler on its context: an output that the assembler also stored, or a
+# context that points back at the assembler whose `_logits` hold the decoder graph, closes a reference cycle
+# through autograd's C++ nodes (output -> grad_fn -> ctx -> assembler -> ...), which Python's collector only
+# breaks late, if at all -- every decode call would pin S[T_max,B,V] and two fp32 [B,V] buffers per step.
+# The contexts hold what the backward needs (softmax, alive bytes) as saved tensors and plain values.
 class _GumbelStep(torch.autograd.Function):
     """One decode step: kernel launch + the dense un-masked sample as the autograd output."""
 
     @staticmethod
     def forward(ctx, logits, noise, asm):
-        ctx.asm, ctx.t = asm, asm._launch_step(logits, noise, True)
-        return asm._rnn_in[ctx.t]
+        y, alive, r = asm._launch_step(logits, noise, True)
+        ctx.save_for_backward(y, alive)
+        ctx.meta = asm._meta()
+        return r
 
     @staticmethod
     def backward(ctx, g_rnn):
         if g_rnn is None:
             return None, None, None
-        return ctx.asm._step_backward(ctx.t, None, g_rnn.contiguous().float()), None, None
+        y, alive = ctx.saved_tensors
+        return _step_backward(ctx.meta, y, alive, None, g_rnn.contiguous().float()), None, None
 
 
 class _Assemble(torch.autograd.Function):
@@ -63,15 +85,17 @@ class _Assemble(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, asm, T, *logits):
-        ctx.asm, ctx.n = asm, len(logits)
+        ctx.n, ctx.meta = len(logits), asm._meta()
+        ctx.save_for_backward(*(asm._y_soft + asm._alive_hist))
         return asm.S[:T]
 
     @staticmethod
     def backward(ctx, dS):
-        asm = ctx.asm
+        saved = ctx.saved_tensors
         grads = []
         for t in range(ctx.n):
-            grads.append(asm._step_backward(t, dS[t + 1], None) if ctx.needs_input_grad[2 + t] else None)
+            grads.append(_step_backward(ctx.meta, saved[t], saved[ctx.n + t], dS[t + 1], None)
+                         if ctx.needs_input_grad[2 + t] else None)
         return (None, None) + tuple(grads)
 
 
@@ -99,7 +123,10 @@ class SoftTokenAssembler:
         self.lens_steps = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.alive = torch.ones((B,), dtype=torch.uint8, device=self.device)
         self.steps = 0
-        self._alive_hist, self._y_soft, self._rnn_in, self._logits = [], [], [], []
+        self._alive_hist, self._y_soft, self._logits = [], [], []
+
+    def _meta(self):
+        return (self.B, self.V, self.kind, self.dtype, self.tau, self.device)
 
     # ---- per step ------------------------------------------------------------------------------
     def step(self, logits, noise=None, want_rnn_in=True):
@@ -126,13 +153,14 @@ class SoftTokenAssembler:
         lg = lg if lg.stride(1) == 1 else lg.contiguous()
         nz = noise.detach().float()
         nz = nz if nz.stride(1) == 1 else nz.contiguous()
-        self._alive_hist.append(self.alive.clone())
+        alive_before = self.alive.clone()        # the kernel updates `alive` in place; the backward needs the old bytes
+        self._alive_hist.append(alive_before)
         y = torch.empty((self.B, self.V), dtype=torch.float32, device=self.device)
         r = torch.empty((self.B, self.V), dtype=torch.float32, device=self.device) if want_rnn_in else None
         a = _lib.SadGumbelArgs()
         a.B, a.V = self.B, self.V
         a.logits, a.logits_stride, a.noise, a.noise_stride = lg.data_ptr(), lg.stride(0), nz.data_ptr(), nz.stride(0)
-        a.tau, a.alive, a.eos_id = self.tau, self.alive.data_ptr(), self.eos_id
+        a.tau, a.alive, a.eos_id = self.tau, alive_before.data_ptr(), self.eos_id
         row = self.S[t + 1]
         a.s_row, a.s_kind, a.s_stride_b = row.data_ptr(), self.kind, row.stride(0)
         a.rnn_in = r.data_ptr() if r is not None else None
@@ -141,20 +169,8 @@ class SoftTokenAssembler:
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().sad_gumbel_st_step(ctypes.byref(a), _stream()), "sad_gumbel_st_step")
         self._y_soft.append(y)
-        self._rnn_in.append(r)
         self.steps += 1
-        return t
-
-    def _step_backward(self, t, d_s_row, g_rnn):
-        dl = torch.empty((self.B, self.V), dtype=torch.float32, device=self.device)
-        if d_s_row is not None and (d_s_row.stride(1) != 1 or d_s_row.dtype != self.dtype):
-            d_s_row = d_s_row.to(self.dtype).contiguous()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.load().sad_gumbel_st_step_bwd(
-                self.B, self.V, _ptr(d_s_row), self.kind, d_s_row.stride(0) if d_s_row is not None else 0, _ptr(g_rnn),
-                _ptr(self._alive_hist[t]), _ptr(self._y_soft[t]), self.tau, _ptr(dl), dl.stride(0), _stream()),
-                "sad_gumbel_st_step_bwd")
-        return dl
+        return y, alive_before, r
 
     @property
     def last_ids(self):
@@ -186,6 +202,8 @@ class SoftTokenAssembler:
                 _ptr(self.S), self.kind, self.S.stride(0), self.S.stride(1), _ptr(self.ids), _ptr(self.val),
                 _ptr(self.lens_steps), _ptr(self.alive), _ptr(lens), _ptr(mask), _stream()), "sad_soft_finalize")
         S = _Assemble.apply(self, T, *self._logits)
+        # the graph now owns what its backward needs; drop the assembler's references to the decoder graph
+        self._logits, self._y_soft, self._alive_hist = [], [], []
         return SoftTokens(S, lens, mask.view(torch.bool), ids, val)
 
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(lib.EXPORTS) == declared
     for name in declared:
         assert hasattr(l, name), name
-    assert l.sad_version() == 211
+    assert l.sad_version() == 300
 
 
 def test_layout_and_padded_dims():

@@ -61,6 +61,15 @@ def _worker(rank, world, port, q):
         out = dp.allreduce_grads([w2, v2])
         assert out.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
         assert torch.allclose(w2.grad, w.grad) and torch.allclose(v2.grad, v.grad)
+        # third form: the two-message reducer the backward's hook drives (dp.OverlappedGradReducer): spans of one
+        # bucket, issued asynchronously in the hook order, complete after finish()
+        flat3 = torch.cat([w.grad.reshape(-1), v.grad.reshape(-1)]).clone() / world
+        red = dp.OverlappedGradReducer()
+        red(flat3[w.numel():], "rest")
+        red(flat3[:w.numel()], "embedding")
+        assert red.finish() == 2 and red.finish() == 0
+        assert red.log == [("rest", v.numel()), ("embedding", w.numel())]
+        assert torch.allclose(flat3[:w.numel()].view_as(w), w.grad) and torch.allclose(flat3[w.numel():], v.grad)
         mean = dp.global_mean_loss(loss_b.sum(), hi - lo)
         q.put((rank, w.grad.numpy().copy(), v.grad.numpy().copy(), dead.grad is None, float(mean)))
     finally:

@@ -1,0 +1,230 @@
+"""Round-3 GPU tests (VERDICT r02 "next round" items 7, 8 and ADVICE r02), all through the C-ABI:
+
+* BASELINE configs[1] at its EXACT shape (B=64, T=23, V=9353, fp32 dense soft tokens, Yelp dev lengths) vs the oracle;
+* the data-parallel gradient hook (two-stage parameter gradients, dp.OverlappedGradReducer's message order);
+* 20 Adam steps of classifier training through the drop-in module beside the fp32 stock-torch port of the reference
+  (oracle/torch_ref.py): bf16-packed weights re-packed every step must track the fp32 loss curve;
+* the producer's decode + backward loop must not grow device memory without gc.collect() (reference cycle through
+  autograd contexts);
+* a hand-off time-out in an UPPER RNN layer is reported by Workspace.check(), and the next sad_forward refuses with the
+  reason read from the library's host-mapped word (no synchronisation)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import sad_oracle as O
+from sad_amd import synth
+from tests.util import relerr, run_sad
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg2_exact_shape_vs_oracle():
+    """transfer/train.sh's shape as BASELINE configs[1] states it: 32-sentence recurrence tiles + small-M stream-K K1 +
+    fp32 S / dS together in one call."""
+    B, T, V, E, H = 64, 23, 9353, 300, 512
+    lengths = synth.yelp_dev_lengths(B, T, seed=1234)
+    params = synth.make_params(V, E, H, seed=21)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=4, kind="dense", time_major=False)
+    mask = synth.transfer_mask(lengths, T)
+    labels = synth.make_labels(B, seed=1234)
+    out = run_sad(params, S, lengths, mask, labels, s_dtype="f32", time_major=True)
+    p = O.cast_params(params, np.float64)
+    f = O.forward(p, S.astype(np.float64), lengths, mask.copy(), True, labels=labels)
+    b = O.backward(p, f["cache"], O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B)))
+    errs = dict(logits=relerr(out["logits"], f["logits"]), weights=relerr(out["weights"], f["weights"]),
+                loss=relerr(out["loss"], f["loss"]), dS=relerr(out["dS"], b["dS"]))
+    print("\n[cfg2 exact shape]", errs)
+    assert np.array_equal(out["mask_after"], f["cache"]["mask"])
+    assert max(errs.values()) < 2e-2, errs
+    for i, ln in enumerate(lengths):
+        assert not out["dS"][i, ln:].any()                      # exact zeros for t >= len
+    assert out["dS_strides"] == out["S_strides"]                # dS keeps the time-major layout of S
+
+
+def test_grad_ready_hook_two_stage_gradients():
+    """functional.GRAD_READY_HOOK: the backward writes [everything but embedding.weight], calls the hook, writes
+    embedding.weight, calls it again; the gradients equal the one-stage ones (atomics' summation order aside)."""
+    from sad_amd import dp, functional as Fn
+    V, E, H, B, T = 9353, 300, 512, 32, 14
+    lengths = synth.make_lengths(B, T, seed=3, lo=2)
+    params = synth.make_params(V, E, H, seed=8)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=3, kind="dense", time_major=False)
+    mask = synth.transfer_mask(lengths, T)
+    labels = synth.make_labels(B, seed=2)
+    ref = run_sad(params, S, lengths, mask, labels, param_grads=True)
+    red = dp.OverlappedGradReducer()
+    Fn.GRAD_READY_HOOK = red
+    try:
+        got = run_sad(params, S, lengths, mask, labels, param_grads=True)
+        live = sum(int(np.prod(params[k].shape)) for k in Fn._LIVE_PARAMS)
+        assert red.log == [("rest", live - V * E), ("embedding", V * E)]
+        assert red.finish() == 0                                # one process: nothing was sent
+        red.log.clear()
+        frozen = run_sad(params, S, lengths, mask, labels, param_grads=True, frozen=("embedding.weight",))
+        assert red.log == [("all", live - V * E)]
+    finally:
+        Fn.GRAD_READY_HOOK = None
+    for k, v in ref["grads"].items():
+        assert relerr(got["grads"][k], v, floor=1e-6) < 1e-4, k
+        if k != "embedding.weight":
+            assert relerr(frozen["grads"][k], v, floor=1e-6) < 1e-4, k
+    assert frozen["grads"]["embedding.weight"] is None
+    assert np.array_equal(got["dS"], ref["dS"])
+
+
+def test_adam_training_20_steps_tracks_fp32_port():
+    """Classifier training as reference classifier/trainers.py:358-374 runs it (hard tokens, mean CE, clip 1.0, Adam):
+    20 optimizer steps through the drop-in module (weights re-packed to bf16 after every step) beside the fp32
+    stock-torch port on the CPU from the same initial parameters and batches.  Band: |loss_gpu - loss_cpu| <= 0.02 +
+    3 % at every step, and both curves must fall."""
+    import torch
+    from types import SimpleNamespace
+    from oracle.torch_ref import TorchRefDiscriminator
+    from sad_amd import classifier_models
+    V, E, H, B, T, STEPS = 2000, 300, 512, 64, 17, 20
+    dev = torch.device("cuda:0")
+    params = synth.make_params(V, E, H, seed=17)
+    cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0, enc_num_layers=1, hidden_size=H,
+                          vocab_size=V, emb_size=E, num_labels=2, freeze_embedding=False, device=str(dev), mask_id=None)
+    gpu = classifier_models.SelfAttnRNNClassifier(cfg)
+    gpu.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    gpu.to(dev).train()
+    cpu = TorchRefDiscriminator(V, E, H, 2, dead_compute=False).load_numpy(params).train()
+    # a learnable rule: the label says whether most content tokens come from the lower half of the vocabulary
+    batches = []
+    for i in range(4):
+        lengths = synth.yelp_dev_lengths(B, T, seed=100 + i)
+        ids = synth.make_token_ids(B, T, V, lengths, seed=100 + i)
+        content = (np.arange(T)[None, :] >= 1) & (np.arange(T)[None, :] < (lengths[:, None] - 1))
+        low = ((ids < V // 2) & content).sum(1)
+        labels = (2 * low > content.sum(1)).astype(np.int64)
+        batches.append((ids, lengths, labels))
+    opt_g = torch.optim.Adam([p for p in gpu.parameters() if p.requires_grad], lr=1e-3)
+    opt_c = torch.optim.Adam([p for p in cpu.parameters() if p.requires_grad], lr=1e-3)
+    curve_g, curve_c = [], []
+    for step in range(STEPS):
+        ids, lengths, labels = batches[step % len(batches)]
+        ln = torch.from_numpy(lengths)
+        # GPU: the drop-in module, classifier flavour (pad mask in, mask derived inside: classifier/models.py:183-187)
+        idt = torch.from_numpy(ids).to(dev)
+        logits, _ = gpu(idt, ln, idt == 0)
+        loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(labels).to(dev))
+        opt_g.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(gpu.parameters(), 1.0)
+        opt_g.step()
+        curve_g.append(float(loss))
+        # CPU: fp32 port, same batch
+        idc = torch.from_numpy(ids)
+        mask = torch.from_numpy(synth.classifier_mask(ids == 0))
+        lg, _ = cpu(idc, ln, mask, soft=False, guard=False)
+        lc = torch.nn.functional.cross_entropy(lg, torch.from_numpy(labels))
+        opt_c.zero_grad()
+        lc.backward()
+        torch.nn.utils.clip_grad_norm_(cpu.parameters(), 1.0)
+        opt_c.step()
+        curve_c.append(float(lc))
+    print("\n[20 Adam steps] gpu:", ["%.4f" % x for x in curve_g])
+    print("[20 Adam steps] cpu:", ["%.4f" % x for x in curve_c])
+    for a, c in zip(curve_g, curve_c):
+        assert np.isfinite(a) and abs(a - c) <= 0.02 + 0.03 * abs(c), (curve_g, curve_c)
+    assert np.mean(curve_g[-4:]) < 0.8 * np.mean(curve_g[:4]) and np.mean(curve_c[-4:]) < 0.8 * np.mean(curve_c[:4])
+    # the dead tensors never received a gradient, so Adam left them alone (reference: grad None)
+    assert gpu.output_bridge.weight.grad is None and gpu.hidden_bridges[1].weight.grad is None
+    assert torch.equal(gpu.output_bridge.weight.detach().cpu(), torch.from_numpy(params["output_bridge.weight"]))
+
+
+def test_producer_decode_loop_does_not_grow_memory():
+    """_GumbelStep returned the tensor the assembler stored and kept the assembler on its context; the
+    cycle ran through autograd's C++ nodes.  Decode (with a stand-in decoder that consumes the previous sample) +
+    backward in a loop, no gc.collect(): memory_allocated() must stay flat."""
+    import gc
+    import torch
+    from sad_amd import producer
+    dev = torch.device("cuda:0")
+    B, V, MAXDEC = 16, 9353, 20
+    W = torch.randn((V, 64), device=dev) * 0.05
+    U = (torch.randn((64, V), device=dev) * 0.05).requires_grad_(True)
+
+    def once():
+        asm = producer.SoftTokenAssembler(B, V, MAXDEC, 0, 1, 2, dev, dtype=torch.bfloat16)
+        prev = torch.zeros((B, V), device=dev)
+        prev[:, 1] = 1.0
+        while asm.keep_decoding():
+            logits = torch.tanh(prev @ W) @ U                    # the "decoder": depends on the previous sample
+            prev = asm.step(logits)
+        soft = asm.finalize()
+        (soft.S.float() * 1e-3).sum().backward()
+        U.grad = None
+
+    gc.disable()
+    try:
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for _ in range(20):
+            once()
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    one_call = (MAXDEC + 3) * B * V * 2
+    assert grown < one_call // 2, "decode loop grew device memory by %.1f MB over 20 calls" % (grown / 1e6)
+
+
+def test_upper_layer_timeout_is_reported_and_next_forward_refuses():
+    """A hand-off time-out in an RNN layer ABOVE the first (only layer 0's words were inspected) and the
+    sync-free report: Workspace.check() sees it, the outputs are NaN, and the next sad_forward on the
+    device returns -4 with the reason -- once; the call after that runs and is clean."""
+    import torch
+    from types import SimpleNamespace
+    from sad_amd import functional as Fn, lib, transfer_models
+    Fn.KEEP_LAST = True
+    dev = torch.device("cuda:0")
+    B, T, V, E, H = 256, 10, 300, 300, 512
+    cfg = SimpleNamespace(cell="LSTM", enc_bidirectional=True, pad_id=0, dropout=0.0, enc_num_layers=2, hidden_size=H,
+                          vocab_size=V, emb_size=E, num_labels=2, freeze_embedding=False, device=str(dev), mask_id=None)
+    params = synth.make_params(V, E, H, seed=3, layers=2)
+    m = transfer_models.SelfAttnRNNClassifier(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m.to(dev)
+    for p in m.parameters():
+        p.requires_grad = False
+    lengths = synth.make_lengths(B, T, seed=5)
+    S0 = torch.from_numpy(synth.make_soft_tokens(B, T, V, lengths, seed=5, kind="dense", time_major=False)).to(dev)
+    ln = torch.from_numpy(lengths)
+    mask0 = torch.from_numpy(synth.transfer_mask(lengths, T)).to(dev)
+    d_up = lib.dims(B, T, 1, 2 * H, H, 2)
+    assert lib.load().sad_uses_half_gates(ctypes.byref(d_up)) == 1, "persistent recurrences expected for the upper layer"
+
+    def run():
+        logits, _ = m(S0, ln, mask0.clone(), soft=True)
+        ws = Fn._Discriminator.last_workspace
+        torch.cuda.synchronize()
+        return logits, ws
+
+    logits0, ws0 = run()
+    ws0.check()
+    assert bool(torch.isfinite(logits0).all())
+    try:
+        lib.debug_set(lib.DBG_SPIN_LIMIT, 2000)
+        lib.debug_set(lib.DBG_WITHHOLD_UPPER_ONLY, 1)
+        lib.debug_set(lib.DBG_WITHHOLD_FWD, 0)
+        logits1, ws1 = run()
+        assert ws1.handoff_timeouts()[0] != 0                       # found in the upper layer's workspace
+        assert ws1.view("SYNC", torch.int32)[-32:-30].tolist() == [0, 0]   # ... not in layer 0's
+        assert bool(torch.isnan(logits1).any())
+        with pytest.raises(RuntimeError, match="timed out"):
+            ws1.check()
+    finally:
+        lib.debug_set(lib.DBG_WITHHOLD_FWD, -1)
+        lib.debug_set(lib.DBG_WITHHOLD_UPPER_ONLY, 0)
+        lib.debug_set(lib.DBG_SPIN_LIMIT, 0)
+    with pytest.raises(RuntimeError, match="EARLIER call"):         # the host-mapped word, read without a sync
+        m(S0, ln, mask0.clone(), soft=True)
+    logits3, ws3 = run()                                            # reported once; this call runs
+    ws3.check()
+    assert torch.equal(logits3, logits0)

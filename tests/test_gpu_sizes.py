@@ -141,8 +141,9 @@ def test_stress_slice_cfg5():
 def test_handoff_timeout_is_loud():
     """A workgroup of a persistent recurrence is withheld (debug setting) and the wait bound made tiny:
     its group's hand-off waits time out.  The call must come back (bounded spins) with NaN logits /
-    loss (forward) resp. NaN d(soft tokens) (BPTT), and Workspace.check() must raise; the next call
-    with the settings restored is clean and identical to the call before."""
+    loss (forward) resp. NaN d(soft tokens) (BPTT), and Workspace.check() must raise; the next sad_forward
+    refuses once with the reason (host-mapped time-out word), the call after it, with the settings restored, is
+    clean and identical to the call before."""
     import torch
     from sad_amd import functional as Fn, lib
     Fn.KEEP_LAST = True
@@ -178,6 +179,10 @@ def test_handoff_timeout_is_loud():
         with pytest.raises(RuntimeError, match="timed out"):
             ws1.check()
         lib.debug_set(lib.DBG_WITHHOLD_FWD, -1)
+        # the recurrence also raised the library's host-mapped word: the next sad_forward on the device refuses
+        # with the reason (no synchronisation involved) and clears it
+        with pytest.raises(RuntimeError, match="EARLIER call on this device timed out"):
+            run()
         lib.debug_set(lib.DBG_WITHHOLD_BWD, 0)
         loss2, logits2, dS2, ws2 = run()
         assert torch.equal(logits2, logits0)                                            # the forward was clean
@@ -189,6 +194,8 @@ def test_handoff_timeout_is_loud():
         lib.debug_set(lib.DBG_WITHHOLD_FWD, -1)
         lib.debug_set(lib.DBG_WITHHOLD_BWD, -1)
         lib.debug_set(lib.DBG_SPIN_LIMIT, 0)
+    with pytest.raises(RuntimeError, match="BPTT of an EARLIER call"):
+        run()
     loss3, logits3, dS3, ws3 = run()
     ws3.check()
     assert torch.equal(logits3, logits0) and torch.equal(dS3, dS0)

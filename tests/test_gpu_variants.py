@@ -9,11 +9,12 @@ import pytest
 
 from oracle import sad_oracle as O
 from sad_amd import synth
-from tests.util import load_golden, relerr
+from tests.util import bf16_round, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
 TOL_FWD, TOL_DS, TOL_WGRAD = 2e-2, 3e-2, 3e-2
+TOL_WGRAD_SAME_WEIGHTS = 1.5e-2      # kernels vs the oracle evaluated with the same bf16-rounded weights (see test_variant_golden)
 VARIANT_TAGS = ["gru_bi", "lstm_uni", "gru_uni", "lstm_bi_l2", "gru_bi_l2", "lstm_uni_l3"]
 
 
@@ -81,6 +82,23 @@ def test_variant_golden(tag):
         errs[k] = relerr(got[k].cpu().numpy(), g, floor=1e-2 if k in ("output_layer.bias", "linear_emb.bias") else 1e-3)
     print("\n%s wgrad errors: %s" % (tag, {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]}))
     assert max(errs.values()) < TOL_WGRAD, errs
+    # Where the 1e-2-level errors above come from: the kernels round the WEIGHTS to bf16 once
+    # (sad_pack_weights).  Against the float64 oracle evaluated with those same bf16-rounded weights (inputs and
+    # activations still exact) the two cancelling bias sums and every other tensor must agree several times tighter,
+    # and the oracle's own shift between exact and rounded weights must explain the gap to the reference fixture.
+    pr = {k: bf16_round(v).astype(np.float64) for k, v in params.items()}
+    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2)).astype(np.float64)
+    fr = O.forward(pr, S_bt, d["lengths"], d["mask"].copy(), True, labels=d["labels"])
+    br = O.backward(pr, fr["cache"], O.ce_dlogits(fr["logits"], d["labels"], np.full((B,), 1.0 / B)), want_param_grads=True)
+    tight, shift = {}, {}
+    for k, g in grads.items():
+        fl = 1e-2 if k in ("output_layer.bias", "linear_emb.bias") else 1e-3
+        tight[k] = relerr(got[k].cpu().numpy(), br["grads"][k], floor=fl)
+        shift[k] = relerr(br["grads"][k], g, floor=fl)
+    worst = max(tight, key=tight.get)
+    print("%s vs oracle with bf16-rounded weights: worst %s %.1e (weight rounding alone moves the oracle by %.1e there; "
+          "largest such shift %.1e)" % (tag, worst, tight[worst], shift[worst], max(shift.values())))
+    assert max(tight.values()) < TOL_WGRAD_SAME_WEIGHTS, tight
     # frozen mode (the transfer loop): same outputs and dS, no parameter gradients
     for p in m.parameters():
         p.requires_grad = False

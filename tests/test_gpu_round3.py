@@ -77,8 +77,8 @@ def test_grad_ready_hook_two_stage_gradients():
 def test_adam_training_20_steps_tracks_fp32_port():
     """Classifier training as reference classifier/trainers.py:358-374 runs it (hard tokens, mean CE, clip 1.0, Adam):
     20 optimizer steps through the drop-in module (weights re-packed to bf16 after every step) beside the fp32
-    stock-torch port on the CPU from the same initial parameters and batches.  Band: |loss_gpu - loss_cpu| <= 0.02 +
-    3 % at every step, and both curves must fall."""
+    stock-torch port on the CPU from the same initial parameters and batches.  Band: |loss_gpu - loss_cpu| <= 0.005 +
+    1 % at every step (measured: <= 1e-4 over a curve that falls from 0.71 to 0.10), and both curves must fall."""
     import torch
     from types import SimpleNamespace
     from oracle.torch_ref import TorchRefDiscriminator
@@ -129,7 +129,7 @@ def test_adam_training_20_steps_tracks_fp32_port():
     print("\n[20 Adam steps] gpu:", ["%.4f" % x for x in curve_g])
     print("[20 Adam steps] cpu:", ["%.4f" % x for x in curve_c])
     for a, c in zip(curve_g, curve_c):
-        assert np.isfinite(a) and abs(a - c) <= 0.02 + 0.03 * abs(c), (curve_g, curve_c)
+        assert np.isfinite(a) and abs(a - c) <= 0.005 + 0.01 * abs(c), (curve_g, curve_c)
     assert np.mean(curve_g[-4:]) < 0.8 * np.mean(curve_g[:4]) and np.mean(curve_c[-4:]) < 0.8 * np.mean(curve_c[:4])
     # the dead tensors never received a gradient, so Adam left them alone (reference: grad None)
     assert gpu.output_bridge.weight.grad is None and gpu.hidden_bridges[1].weight.grad is None

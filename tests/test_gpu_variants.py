@@ -9,12 +9,11 @@ import pytest
 
 from oracle import sad_oracle as O
 from sad_amd import synth
-from tests.util import bf16_round, load_golden, relerr
+from tests.util import load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
-TOL_FWD, TOL_DS, TOL_WGRAD = 2e-2, 3e-2, 3e-2
-TOL_WGRAD_SAME_WEIGHTS = 1.5e-2      # kernels vs the oracle evaluated with the same bf16-rounded weights (see test_variant_golden)
+TOL_FWD, TOL_DS, TOL_WGRAD = 2e-2, 3e-2, 2e-2
 VARIANT_TAGS = ["gru_bi", "lstm_uni", "gru_uni", "lstm_bi_l2", "gru_bi_l2", "lstm_uni_l3"]
 
 
@@ -73,32 +72,35 @@ def test_variant_golden(tag):
     got = {k: p.grad for k, p in m.named_parameters()}
     for k in hdr["none_grads"]:
         assert got[k] is None, k
-    errs = {}
+    # Two of the gradients are CANCELLING sums: d output_layer.bias = sum_b dlogits_b and d linear_emb.bias = sum over
+    # tokens of dKk are ~2e-3 here while their summands are ~1e-1.  Their error is set by the summands, not by the
+    # sum: the kernels add bf16-rounded dKk entries (relative 2^-9 each) and softmax terms computed from logits that
+    # carry the forward tolerance.  So they are checked against bounds built from the oracle's own summands
+    #   |err_j| <= 2^-8 * sum_tokens |dKk[., j]|      resp.      |err_l| <= TOL_FWD * sum_b |dlogits[b, l]|
+    # (twice the worst case of rounding every dKk entry to bf16; the forward tolerance applied to every term), and
+    # every other tensor at TOL_WGRAD relative to its own largest entry.  (round 2 used a flat
+    # floor of 1e-2 for these two; against the oracle evaluated with bf16-ROUNDED WEIGHTS they do not get closer
+    # -- 3.4e-4 absolute for gru_bi -- i.e. it is the activation rounding, which these bounds model.)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2)).astype(np.float64)
+    fo = O.forward(p64, S_bt, d["lengths"], d["mask"].copy(), True, labels=d["labels"])
+    dl = O.ce_dlogits(fo["logits"], d["labels"], np.full((B,), 1.0 / B))
+    bo = O.backward(p64, fo["cache"], dl, want_param_grads=True)
+    bounds = {"linear_emb.bias": 2.0 ** -8 * np.abs(bo["dKk"]).sum(axis=(0, 1)),
+              "output_layer.bias": TOL_FWD * np.abs(dl).sum(axis=0)}
+    errs, used = {}, {}
     for k, g in grads.items():
         assert got[k] is not None and tuple(got[k].shape) == g.shape, k
-        # (floor for the two cancelling sums: d output_layer.bias = sum_b (p_b - y_b) / B and d linear_emb.bias =
-        # sum over tokens of dKk are ~2e-3 here while their terms are ~1e-1, so the bf16-level error of the logits
-        # / of dKk shows up at 1e-4 absolute; below the floor the comparison is absolute)
-        errs[k] = relerr(got[k].cpu().numpy(), g, floor=1e-2 if k in ("output_layer.bias", "linear_emb.bias") else 1e-3)
-    print("\n%s wgrad errors: %s" % (tag, {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]}))
+        if k in bounds:
+            diff = np.abs(got[k].cpu().numpy().astype(np.float64) - g)
+            used[k] = float((diff / bounds[k]).max())
+            assert used[k] < 1.0, (k, diff, bounds[k])
+        else:
+            errs[k] = relerr(got[k].cpu().numpy(), g, floor=1e-3)
+    print("\n%s wgrad errors: %s; cancelling sums, share of their rounding bound used: %s"
+          % (tag, {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:5]},
+             {k: "%.2f" % v for k, v in used.items()}))
     assert max(errs.values()) < TOL_WGRAD, errs
-    # Where the 1e-2-level errors above come from: the kernels round the WEIGHTS to bf16 once
-    # (sad_pack_weights).  Against the float64 oracle evaluated with those same bf16-rounded weights (inputs and
-    # activations still exact) the two cancelling bias sums and every other tensor must agree several times tighter,
-    # and the oracle's own shift between exact and rounded weights must explain the gap to the reference fixture.
-    pr = {k: bf16_round(v).astype(np.float64) for k, v in params.items()}
-    S_bt = np.ascontiguousarray(d["S"].transpose(1, 0, 2)).astype(np.float64)
-    fr = O.forward(pr, S_bt, d["lengths"], d["mask"].copy(), True, labels=d["labels"])
-    br = O.backward(pr, fr["cache"], O.ce_dlogits(fr["logits"], d["labels"], np.full((B,), 1.0 / B)), want_param_grads=True)
-    tight, shift = {}, {}
-    for k, g in grads.items():
-        fl = 1e-2 if k in ("output_layer.bias", "linear_emb.bias") else 1e-3
-        tight[k] = relerr(got[k].cpu().numpy(), br["grads"][k], floor=fl)
-        shift[k] = relerr(br["grads"][k], g, floor=fl)
-    worst = max(tight, key=tight.get)
-    print("%s vs oracle with bf16-rounded weights: worst %s %.1e (weight rounding alone moves the oracle by %.1e there; "
-          "largest such shift %.1e)" % (tag, worst, tight[worst], shift[worst], max(shift.values())))
-    assert max(tight.values()) < TOL_WGRAD_SAME_WEIGHTS, tight
     # frozen mode (the transfer loop): same outputs and dS, no parameter gradients
     for p in m.parameters():
         p.requires_grad = False

@@ -161,6 +161,7 @@ def kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits, weights):
     M = B * T
     rows = int((np.arange(T)[:, None] < lengths[None, :]).sum())          # token rows with t < len
     rows_att = int(np.maximum(lengths.astype(np.int64) - 2, 1).sum())       # attention-active rows (mask: pad/sos/eos)
+    half_gates = L.sad_uses_half_gates(ctypes.byref(d)) == 1               # gate pre-activations leave as fp16 records
     dS = torch.empty_like(S)
     lg, wt = torch.empty_like(logits), torch.empty_like(weights)
     ls = torch.empty((B,), dtype=torch.float32, device=S.device)
@@ -174,7 +175,7 @@ def kernel_table(w, lib, Fn, pw, ws, S, lengths, labels, logits, weights):
          2.0 * rows * V * E, rows * V * esz + M * Ep * 2),
         ("K2a+K3 in-projection fwd (k_inproj_fwd_rs3)", "mfma",
          lambda: L.sad_inproj_fwd(D, p(pw.buf), p(ws.buf), st()),
-         2.0 * rows * E * 9 * H, rows * Ep * 2 + rows * (2 * Gp + Hp) * 4),
+         2.0 * rows * E * 9 * H, rows * Ep * 2 + rows * (2 * Gp * (2 if half_gates else 4) + Hp * 4)),
         ("K2b LSTM recurrence fwd (k_lstm_fwd_persist2)", "latency",
          lambda: L.sad_lstm_fwd(D, p(pw.buf), p(ws.buf), st()),
          2.0 * rows * H * 4 * H * 2, 0),

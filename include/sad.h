@@ -215,8 +215,11 @@ size_t sad_packed_bytes(const sad_dims* d);
 size_t sad_workspace_bytes(const sad_dims* d);
 int sad_workspace_field(const sad_dims* d, int field, size_t* offset, size_t* bytes);
 /* 1 when, for these dims on the current device, the recurrences run as persistent kernels and keep
- * the activated LSTM gates as fp16 in SAD_WS_GA (G then holds the pre-activations of
- * transfer/models.py:906's nn.LSTM input GEMM); 0 when the activated gates are fp32 in SAD_WS_G. */
+ * the activated LSTM gates as fp16 records in SAD_WS_GA; 0 when the activated gates are fp32 in SAD_WS_G.
+ * In the first case, at the shipped embedding size (E = 289..320), the gate pre-activations of
+ * transfer/models.py:906's nn.LSTM input GEMM are fp16 records in SAD_WS_GA too (the input projection writes the
+ * record that the forward recurrence reads and then overwrites with the activated gates) and SAD_WS_G is unused;
+ * at other sizes (e.g. the 2H-wide input of an upper RNN layer) they are fp32 rows of SAD_WS_G. */
 int sad_uses_half_gates(const sad_dims* d);
 
 /* state_dict fp32 -> packed image.  Replaces nothing in the reference (it consumes fp32 parameters
@@ -277,11 +280,13 @@ int sad_softemb_fwd(const sad_dims* d, const void* packed, const void* src, int3
 int sad_softemb_bwd(const sad_dims* d, const void* packed, void* dsrc, int32_t dsrc_kind,
                     int64_t dsrc_stride_b, int64_t dsrc_stride_t, void* workspace, void* stream);
 /* sad_inproj_fwd:   input projection of both LSTM directions + linear_emb keys in one GEMM (reference
- *                   transfer/models.py:906 nn.LSTM's W_ih products, :925): workspace X -> G, KK.
+ *                   transfer/models.py:906 nn.LSTM's W_ih products, :925): workspace X -> G (or GA records, see
+ *                   sad_uses_half_gates), KK.
  * sad_inproj_bwd:   its autograd: workspace DZ -> DX.
  * sad_lstm_fwd:     the packed BiLSTM recurrence (reference transfer/models.py:904-906, ctor :779-785):
- *                   workspace G (gate pre-activations of the input projection) + LENS -> HS, CS and the
- *                   activated gates (GA, or G in place when sad_uses_half_gates() == 0).
+ *                   workspace G / GA (gate pre-activations of the input projection) + LENS -> HS, CS and the
+ *                   activated gates (GA, or G in place when sad_uses_half_gates() == 0).  With pre-activation
+ *                   records in GA the stage consumes them: run sad_inproj_fwd again before repeating it.
  * sad_lstm_bwd:     its BPTT (autograd of :906): workspace DHFIN + saved gates / cell states -> gate columns
  *                   of DZ.
  * sad_attnpool_fwd: additive attention + masked softmax + pooling + head (+ CE) (reference

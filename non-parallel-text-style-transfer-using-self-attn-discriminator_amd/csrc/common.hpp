@@ -115,6 +115,39 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_or<0x143, 0xc>(v, -INFINITY));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// Activated gates of the persistent recurrences: fp16 records of [unit][i, f, g, o] (SAD_WS_GA).  The
+// values lie in [-1, 1] (the GRU's fourth slot, W_hn h + b_hn, is O(1)), so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
+// anyway); a lane's 4 units x 4 gates are 32 contiguous bytes.  Halves the gate stores of the forward
+// recurrence (47 us of its 305 at cfg3 were these stores) and the gate loads of the BPTT.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Record (4 units x 4 gates, 32 bytes) of sentence b, unit quad j/4 at step t: [t][dir][16-sentence
+// block][quad][16 sentences][16 halves] -- the lane mapping of both recurrences is lane & 15 = sentence,
+// lane >> 4 = quad, so a wave instruction covers 2 KB of contiguous bytes (row-major records gave 16
+// cache lines per quarter wave, the fragment-shaped access the hand-off images avoid).
+__host__ __device__ inline size_t ga_bytes(int T, int B, int Hp) { return (size_t)T * 2 * ((B + 15) / 16 * 16) * Hp * 4 * 2; }
+__device__ __forceinline__ long long ga_index(int t, int dir, int b, int j, int B, int Hp) {
+    const int sblocks = (B + 15) >> 4;
+    return (((((long long)t * 2 + dir) * sblocks + (b >> 4)) * (Hp >> 2) + (j >> 2)) * 16 + (b & 15)) * 16;
+}
+__device__ __forceinline__ void ga_store(unsigned short* p, const f32x4& gi, const f32x4& gf, const f32x4& gg, const f32x4& go) {
+    f16x8 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        lo[4 * e + 0] = (_Float16)gi[e]; lo[4 * e + 1] = (_Float16)gf[e]; lo[4 * e + 2] = (_Float16)gg[e]; lo[4 * e + 3] = (_Float16)go[e];
+        hi[4 * e + 0] = (_Float16)gi[2 + e]; hi[4 * e + 1] = (_Float16)gf[2 + e]; hi[4 * e + 2] = (_Float16)gg[2 + e]; hi[4 * e + 3] = (_Float16)go[2 + e];
+    }
+    *(f16x8*)p = lo;
+    *(f16x8*)(p + 8) = hi;
+}
+__device__ __forceinline__ void ga_unpack(const u32x4& rlo, const u32x4& rhi, f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go) {
+    const f16x8 lo = __builtin_bit_cast(f16x8, rlo), hi = __builtin_bit_cast(f16x8, rhi);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        gi[e] = (float)lo[4 * e + 0]; gf[e] = (float)lo[4 * e + 1]; gg[e] = (float)lo[4 * e + 2]; go[e] = (float)lo[4 * e + 3];
+        gi[2 + e] = (float)hi[4 * e + 0]; gf[2 + e] = (float)hi[4 * e + 1]; gg[2 + e] = (float)hi[4 * e + 2]; go[2 + e] = (float)hi[4 * e + 3];
+    }
+}
 #endif
 
 }  // namespace sad

@@ -2267,7 +2267,13 @@ template <int KS>
 __global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* __restrict__ X,
                                                        const int* __restrict__ rows, const int* __restrict__ nrows,
                                                        const bf16raw* __restrict__ wcat, const float* __restrict__ bcat,
-                                                       float* __restrict__ G, float* __restrict__ Kk) {
+                                                       float* __restrict__ G, float* __restrict__ Kk,
+                                                       unsigned short* __restrict__ GA) {
+    // GA != NULL (the persistent recurrences run, sad_uses_half_gates): the gate pre-activations leave as fp16
+    // RECORDS in SAD_WS_GA -- the record the forward recurrence's lane for (sentence, unit quad) reads and then
+    // overwrites with its activated gates -- instead of fp32 rows of G: half the bytes of this store-bound kernel,
+    // and in the accumulator layout a lane already holds exactly one record per row (4 gate tiles x 4 units), so the
+    // gate tiles skip the LDS turn.  The attention keys (last Hp columns) stay fp32 rows of Kk.
     extern __shared__ __attribute__((aligned(16))) unsigned char ip_lds[];
     unsigned char* Bs = ip_lds;                                          // 2 x 64 * KS * 64 bytes (two W tile buffers)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2299,8 +2305,28 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* 
             const int j = j0 + (lane >> 4) + 4 * i;
             srow[i] = j < n ? rows[j] : -1;
         }
+        // record base of this lane's two rows (fragment side): everything of ga_index but direction and unit quad
+        long long garow[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int m = mrow[tm] < M ? mrow[tm] : 0, t = m / s.B, b = m - t * s.B;
+            garow[tm] = ga_index(t, 0, b, 0, s.B, s.Hp);
+        }
+        const long long gadir = (long long)((s.B + 15) >> 4) * (s.Hp >> 2) * 256;     // ga_index(t, 1, ..) - ga_index(t, 0, ..)
         rs_gemm<KS, 2, true>(X, M, mrow, wave_any, 1, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
             if (!wave_any) return;
+            if (GA != nullptr && nt * 64 < G2) {
+                const int dir = nt * 64 >= s.Gp ? 1 : 0, ub = nt - dir * (s.Gp >> 6), q = lane >> 4;
+                f32x4 bias[4];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) bias[tn] = *(const f32x4*)&bcat[nt * 64 + tn * 16 + 4 * q];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+                    if (mrow[tm] < M)
+                        ga_store(GA + garow[tm] + dir * gadir + (long long)(ub * 4 + q) * 256, acc[tm][0] + bias[0],
+                                 acc[tm][1] + bias[1], acc[tm][2] + bias[2], acc[tm][3] + bias[3]);
+                return;
+            }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 const int r = tm * 16 + (lane & 15);

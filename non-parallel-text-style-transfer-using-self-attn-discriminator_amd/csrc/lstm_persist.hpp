@@ -57,38 +57,6 @@ __device__ __forceinline__ u32x4 lp_pair16(u32x2 x, u32x2 y) {
 __device__ __forceinline__ void lp_store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16 /* sc1 */);
 }
-// Activated gates of the persistent recurrences: fp16 records of [unit][i, f, g, o] (SAD_WS_GA).  The
-// values lie in [-1, 1] (the GRU's fourth slot, W_hn h + b_hn, is O(1)), so fp16 keeps 11 significant bits (the BPTT rounds its results to bf16
-// anyway); a lane's 4 units x 4 gates are 32 contiguous bytes.  Halves the gate stores of the forward
-// recurrence (47 us of its 305 at cfg3 were these stores) and the gate loads of the BPTT.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// Record (4 units x 4 gates, 32 bytes) of sentence b, unit quad j/4 at step t: [t][dir][16-sentence
-// block][quad][16 sentences][16 halves] -- the lane mapping of both recurrences is lane & 15 = sentence,
-// lane >> 4 = quad, so a wave instruction covers 2 KB of contiguous bytes (row-major records gave 16
-// cache lines per quarter wave, the fragment-shaped access the hand-off images avoid).
-__host__ __device__ inline size_t ga_bytes(int T, int B, int Hp) { return (size_t)T * 2 * ((B + 15) / 16 * 16) * Hp * 4 * 2; }
-__device__ __forceinline__ long long ga_index(int t, int dir, int b, int j, int B, int Hp) {
-    const int sblocks = (B + 15) >> 4;
-    return (((((long long)t * 2 + dir) * sblocks + (b >> 4)) * (Hp >> 2) + (j >> 2)) * 16 + (b & 15)) * 16;
-}
-__device__ __forceinline__ void ga_store(unsigned short* p, const f32x4& gi, const f32x4& gf, const f32x4& gg, const f32x4& go) {
-    f16x8 lo, hi;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        lo[4 * e + 0] = (_Float16)gi[e]; lo[4 * e + 1] = (_Float16)gf[e]; lo[4 * e + 2] = (_Float16)gg[e]; lo[4 * e + 3] = (_Float16)go[e];
-        hi[4 * e + 0] = (_Float16)gi[2 + e]; hi[4 * e + 1] = (_Float16)gf[2 + e]; hi[4 * e + 2] = (_Float16)gg[2 + e]; hi[4 * e + 3] = (_Float16)go[2 + e];
-    }
-    *(f16x8*)p = lo;
-    *(f16x8*)(p + 8) = hi;
-}
-__device__ __forceinline__ void ga_unpack(const u32x4& rlo, const u32x4& rhi, f32x4& gi, f32x4& gf, f32x4& gg, f32x4& go) {
-    const f16x8 lo = __builtin_bit_cast(f16x8, rlo), hi = __builtin_bit_cast(f16x8, rhi);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        gi[e] = (float)lo[4 * e + 0]; gf[e] = (float)lo[4 * e + 1]; gg[e] = (float)lo[4 * e + 2]; go[e] = (float)lo[4 * e + 3];
-        gi[2 + e] = (float)hi[4 * e + 0]; gf[2 + e] = (float)hi[4 * e + 1]; gg[2 + e] = (float)hi[4 * e + 2]; go[2 + e] = (float)hi[4 * e + 3];
-    }
-}
 __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
 }
@@ -183,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
                                                           unsigned short* __restrict__ GA, unsigned* sync,
-                                                          unsigned spin_limit, int withhold, int bm, unsigned* hostflag) {
+                                                          unsigned spin_limit, int withhold, int bm, unsigned* hostflag,
+                                                          int ga_pre) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lp_lds[];
     const int Hp = s.Hp, Gp = s.Gp, B = s.B, T = s.T;
     bf16raw* Wl = (bf16raw*)lp_lds;                          // [64][Hp], chunk-swizzled
@@ -271,9 +240,16 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (act[tm]) {
-                const float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
+                if (ga_pre) {
+                    // the in-projection left the pre-activations as fp16 records in GA, in this lane's own record
+                    // (the activated gates overwrite it below): 32 bytes instead of 64 of fp32 G
+                    const unsigned short* ga = GA + ga_index(t, dir, brow[tm], j, B, Hp);
+                    ga_unpack(*(const u32x4*)ga, *(const u32x4*)(ga + 8), acc[tm][0], acc[tm][1], acc[tm][2], acc[tm][3]);
+                } else {
+                    const float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) acc[tm][gq] = *(const f32x4*)(g + 16 * gq);
+                    for (int gq = 0; gq < 4; ++gq) acc[tm][gq] = *(const f32x4*)(g + 16 * gq);
+                }
             }
         }
         LF_PROF_T(0)

@@ -448,6 +448,11 @@ bool half_gates(const Shape& s) {
     return lstm_fwd_persist_fits(s, &g1) && lstm_bwd_persist_fits(s, &g2);
 }
 
+// The in-projection writes the gate pre-activations as fp16 records straight into SAD_WS_GA (and the forward
+// recurrence reads them there) when the A-stationary in-projection kernel runs AND both recurrences are persistent;
+// otherwise they are fp32 rows of SAD_WS_G.
+bool ga_preact(const Shape& s) { return s.Ep == 320 && s.Ncat % 64 == 0 && half_gates(s); }
+
 // sad_pack_weights collects its jobs here and launches them together (k_pack_all)
 struct PackBatch {
     PackJobs jobs;
@@ -642,7 +647,8 @@ int run_inproj_fwd(const Ctx& c) {
         const int grid = units < cus ? (int)units : cus;
         hipLaunchKernelGGL((k_inproj_fwd_rs3<10>), dim3(grid), dim3(512), lds, c.st, s, X,
                            at<int>(c.ws, c.wl.off[SAD_WS_ROWS]), at<int>(c.ws, c.wl.off[SAD_WS_NROWS]),
-                           at<bf16raw>(c.packed, c.pl.wcat), at<float>(c.packed, c.pl.bcat), G, Kk);
+                           at<bf16raw>(c.packed, c.pl.wcat), at<float>(c.packed, c.pl.bcat), G, Kk,
+                           ga_preact(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr);
     } else {
         typedef CfgSquare C;
         dim3 grid(ceil_div(s.Ncat, C::BN), ceil_div(s.M, C::BM));
@@ -670,7 +676,7 @@ int run_lstm_fwd(const Ctx& c) {
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
                            (c.upper || !g_withhold_upper_only.load(std::memory_order_relaxed)) ? g_withhold_fwd.load(std::memory_order_relaxed) : -1,
-                           lstm_fwd_bm(s), hostflag_dev());
+                           lstm_fwd_bm(s), hostflag_dev(), ga_preact(s) ? 1 : 0);
     } else {
         for (int step = 0; step < s.T; ++step) {
             if (s.B >= 512) {

@@ -314,18 +314,23 @@ def test_stage_entry_points_and_joint_upstream_gradients():
     d = ws.d
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
-    assert L.sad_uses_half_gates(ctypes.byref(d)) == 1        # G keeps the pre-activations: the recurrence can be re-run
+    assert L.sad_uses_half_gates(ctypes.byref(d)) == 1
     hs0 = ws.view("HS", torch.bfloat16).clone()
     cs0 = ws.view("CS", torch.float32).clone()
     dz0 = ws.view("DZ", torch.bfloat16).clone()
     live = (ws.view("NEED", torch.uint8).reshape(T, B) & 1).bool()
     ws.view("HS", torch.bfloat16).zero_()
+    # the recurrence consumed the pre-activation records of GA (it overwrites them with the activated gates): the
+    # in-projection stage rebuilds them from X, then the recurrence stage can run again
+    ga0 = ws.view("GA", torch.int16).clone()               # (bit patterns: rows nobody writes hold whatever was there)
+    lib.check(L.sad_inproj_fwd(ctypes.byref(d), ptr(pw.buf), ptr(ws.buf), st), "sad_inproj_fwd")
     lib.check(L.sad_lstm_fwd(ctypes.byref(d), ptr(pw.buf), ptr(ws.buf), st), "sad_lstm_fwd")
     torch.cuda.synchronize()
     ws.check()
     hp = ws.d.H + (-ws.d.H) % 32
     assert torch.equal(ws.view("HS", torch.bfloat16).reshape(T, B, 2 * hp)[live], hs0.reshape(T, B, 2 * hp)[live])
     assert torch.equal(ws.view("CS", torch.float32).reshape(T, B, 2 * hp)[live], cs0.reshape(T, B, 2 * hp)[live])
+    assert torch.equal(ws.view("GA", torch.int16), ga0)       # activated gate records, bit for bit
     lg2 = torch.empty_like(logits)
     w2 = torch.empty_like(w)
     ls2 = torch.empty_like(loss)

@@ -3,6 +3,7 @@
 #include "../../include/sad.h"
 #include "kernels.hpp"
 #include "wgrad.hpp"
+#include "wgrad2.hpp"
 #include "lstm_persist.hpp"
 #include "producer.hpp"
 
@@ -1231,8 +1232,53 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         return want < 1 ? 1 : want;
     };
 
+    // Second-generation kernels (wgrad2.hpp: 128-column tiles, LDS-direct operand loads) at the shipped sizes
+    const bool gen2 = s.Ep == 320 && s.Hp % 256 == 0;
+    // row splits of a gen-2 launch: about one workgroup per CU; a workgroup keeps the row indices of its slice in
+    // LDS behind the two operand stages, so slices are also bounded by what is left of the 160 KB
+    auto split2 = [&](int tiles, int stage_bytes, size_t* lds) {
+        const int cus = device_cus();
+        int zs = cus / (tiles < 1 ? 1 : tiles);
+        if (zs < 1) zs = 1;
+        const int cap = (int)((163840 - (size_t)stage_bytes) / 4) / 64 * 64;      // list positions that fit
+        const int stages = ceil_div(s.M, 64);
+        while (ceil_div(stages, zs) * 64 > cap) ++zs;
+        if (zs > stages) zs = stages;
+        *lds = (size_t)stage_bytes + (((size_t)ceil_div(stages, zs) * 64 * 4 + 4095) & ~(size_t)4095);
+        return zs;
+    };
+
+    // partial tiles go to the stream-K slab of K1 (idle here) and a second launch adds them up in fixed order; when a
+    // launch's partial tiles do not fit the slab (very large M: many row splits) it falls back to fp32 atomics
+    float* slab_all = wl.bytes[SAD_WS_K1SLABS] != 0 ? at<float>(ws, wl.off[SAD_WS_K1SLABS]) : nullptr;
+    auto slab_for = [&](long long tiles, int zs, long long tile_floats) {
+        return (size_t)tiles * zs * tile_floats * 4 <= wl.bytes[SAD_WS_K1SLABS] ? slab_all : (float*)nullptr;
+    };
+    W2Out wo = {g->embedding_weight, g->rnn_weight_ih[0], g->rnn_weight_ih[1], g->linear_emb_weight,
+                CatBias{nullptr, nullptr, nullptr, nullptr, nullptr}, g->rnn_weight_hh[0], g->rnn_weight_hh[1]};
+
     // d embedding.weight
-    if (g->embedding_weight != nullptr) {
+    if (g->embedding_weight != nullptr && gen2 && (src_kind == SAD_SRC_F32 || src_kind == SAD_SRC_BF16)) {
+        if (check_ptr(src, "src") || check_aligned(src, src_kind == SAD_SRC_F32 ? 4 : 2, "src")) return -1;
+        const int t1 = ceil_div(s.V, W2Emb::BN1), xt = ceil_div(t1, 8);
+        size_t lds = 0;
+        const int zs = split2(t1, W2Emb::LDS_BYTES, &lds);
+        const dim3 grid(8 * xt, 1, zs);
+        float* slab = slab_for(t1, zs, wgrad2_tile_floats<W2Emb>());
+        if (src_kind == SAD_SRC_F32) {
+            allow_lds((const void*)k_wgrad2_emb<SRC_F32>, lds, 512);
+            hipLaunchKernelGGL(k_wgrad2_emb<SRC_F32>, grid, dim3(512), lds, st, s, src, (long long)sT, (long long)sB, DX, rows,
+                               nrows, g->embedding_weight, xt, slab, t1);
+        } else {
+            allow_lds((const void*)k_wgrad2_emb<SRC_BF16>, lds, 512);
+            hipLaunchKernelGGL(k_wgrad2_emb<SRC_BF16>, grid, dim3(512), lds, st, s, src, (long long)sT, (long long)sB, DX, rows,
+                               nrows, g->embedding_weight, xt, slab, t1);
+        }
+        if (slab != nullptr)
+            hipLaunchKernelGGL((k_wgrad2_reduce<W2Emb, W2_EMB>), dim3(t1, 8 * W2Emb::T1 * W2Emb::T2 * 64 / 256), dim3(256), 0, st, s,
+                               slab, nrows, t1, zs, wo, 1, -1);
+        SAD_CHECK_LAUNCH("k_wgrad2_emb");
+    } else if (g->embedding_weight != nullptr) {
         if (check_ptr(src, "src")) return -1;
         if (src_kind == SAD_SRC_IDS) {
             if (check_aligned(src, 8, "src")) return -1;
@@ -1281,7 +1327,21 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
             cb = CatBias{g->rnn_bias_ih[0], g->rnn_bias_hh[0], g->rnn_bias_ih[1], g->rnn_bias_hh[1], g->linear_emb_bias};
             bias_done = true;
         }
-        if (s.Ep == 320) {
+        if (gen2) {
+            const int t1 = s.Ncat / W2Cat::BN1;
+            size_t lds = 0;
+            const int zs = split2(t1, W2Cat::LDS_BYTES, &lds);
+            allow_lds((const void*)k_wgrad2_cat, lds, 512);
+            float* slab = slab_for(t1, zs, wgrad2_tile_floats<W2Cat>());
+            hipLaunchKernelGGL(k_wgrad2_cat, dim3(t1, 1, zs), dim3(512), lds, st, s, DZ, X, rows, nrows, g->rnn_weight_ih[0],
+                               g->rnn_weight_ih[1], g->linear_emb_weight, cb, slab);
+            if (slab != nullptr) {
+                wo.cb = cb;
+                const bool ones = cb.bih0 != nullptr || cb.bhh0 != nullptr || cb.bih1 != nullptr || cb.bhh1 != nullptr || cb.blin != nullptr;
+                hipLaunchKernelGGL((k_wgrad2_reduce<W2Cat, W2_CAT>), dim3(t1, 8 * W2Cat::T1 * W2Cat::T2 * 64 / 256), dim3(256), 0, st,
+                                   s, slab, nrows, t1, zs, wo, 1, ones && s.E < s.Ep ? s.E : -1);
+            }
+        } else if (s.Ep == 320) {
             typedef WCfg<64, 320, 2, 4> W;
             const int t1 = ceil_div(s.Ncat, W::BN1);
             launch_wg<W>(k_wgrad_cat<W>, dim3(t1, 1, row_split(s.M, t1)), st, s, DZ, X, rows, nrows, g->rnn_weight_ih[0],
@@ -1295,7 +1355,19 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         SAD_CHECK_LAUNCH("k_wgrad_cat");
     }
     // d rnn.weight_hh (both directions)
-    if (g->rnn_weight_hh[0] != nullptr || g->rnn_weight_hh[1] != nullptr) {
+    if ((g->rnn_weight_hh[0] != nullptr || g->rnn_weight_hh[1] != nullptr) && gen2) {
+        const int t1 = s.Gp / W2Hh::BN1, t2 = s.Hp / W2Hh::BN2;
+        size_t lds = 0;
+        const int zs = split2(2 * t1 * t2, W2Hh::LDS_BYTES, &lds);
+        allow_lds((const void*)k_wgrad2_hh, lds, 512);
+        float* slab = slab_for(2 * t1 * t2, zs, wgrad2_tile_floats<W2Hh>());
+        hipLaunchKernelGGL(k_wgrad2_hh, dim3(t1, t2, 2 * zs), dim3(512), lds, st, s, DZ, Hs, rows, nrows, g->rnn_weight_hh[0],
+                           g->rnn_weight_hh[1], slab);
+        if (slab != nullptr)
+            hipLaunchKernelGGL((k_wgrad2_reduce<W2Hh, W2_HH>), dim3(2 * t1 * t2, 8 * W2Hh::T1 * W2Hh::T2 * 64 / 256), dim3(256), 0, st,
+                               s, slab, nrows, 2 * t1 * t2, zs, wo, t2, -1);
+        SAD_CHECK_LAUNCH("k_wgrad2_hh");
+    } else if (g->rnn_weight_hh[0] != nullptr || g->rnn_weight_hh[1] != nullptr) {
         typedef WCfg<128, 256, 2, 4> W;
         const int t1 = ceil_div(s.Gp, W::BN1), t2 = ceil_div(s.Hp, W::BN2);
         launch_wg<W>(k_wgrad_hh<W>, dim3(t1, t2, 2 * row_split(s.M, 2 * t1 * t2)), st, s, DZ, Hs, rows, nrows,

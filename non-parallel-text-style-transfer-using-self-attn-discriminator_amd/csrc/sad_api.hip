@@ -1232,19 +1232,16 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         return want < 1 ? 1 : want;
     };
 
-    // Second-generation kernels (wgrad2.hpp: 128-column tiles, LDS-direct operand loads) at the shipped sizes
-    const bool gen2 = s.Ep == 320 && s.Hp % 256 == 0;
-    // row splits of a gen-2 launch: about one workgroup per CU; a workgroup keeps the row indices of its slice in
-    // LDS behind the two operand stages, so slices are also bounded by what is left of the 160 KB
+    // Second-generation kernels (wgrad2.hpp: 128-column tiles, three wave roles, LDS-direct loads) at the shipped sizes
+    const bool gen2 = s.Ep == 320 && s.Hp % 256 == 0 && s.V >= 128;
+    // row splits of a gen-2 launch: about one workgroup per CU
     auto split2 = [&](int tiles, int stage_bytes, size_t* lds) {
         const int cus = device_cus();
         int zs = cus / (tiles < 1 ? 1 : tiles);
         if (zs < 1) zs = 1;
-        const int cap = (int)((163840 - (size_t)stage_bytes) / 4) / 64 * 64;      // list positions that fit
         const int stages = ceil_div(s.M, 64);
-        while (ceil_div(stages, zs) * 64 > cap) ++zs;
         if (zs > stages) zs = stages;
-        *lds = (size_t)stage_bytes + (((size_t)ceil_div(stages, zs) * 64 * 4 + 4095) & ~(size_t)4095);
+        *lds = (size_t)stage_bytes;
         return zs;
     };
 
@@ -1266,12 +1263,12 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         const dim3 grid(8 * xt, 1, zs);
         float* slab = slab_for(t1, zs, wgrad2_tile_floats<W2Emb>());
         if (src_kind == SAD_SRC_F32) {
-            allow_lds((const void*)k_wgrad2_emb<SRC_F32>, lds, 512);
-            hipLaunchKernelGGL(k_wgrad2_emb<SRC_F32>, grid, dim3(512), lds, st, s, src, (long long)sT, (long long)sB, DX, rows,
+            allow_lds((const void*)k_wgrad2_emb<SRC_F32>, lds, 1024);
+            hipLaunchKernelGGL(k_wgrad2_emb<SRC_F32>, grid, dim3(1024), lds, st, s, src, (long long)sT, (long long)sB, DX, rows,
                                nrows, g->embedding_weight, xt, slab, t1);
         } else {
-            allow_lds((const void*)k_wgrad2_emb<SRC_BF16>, lds, 512);
-            hipLaunchKernelGGL(k_wgrad2_emb<SRC_BF16>, grid, dim3(512), lds, st, s, src, (long long)sT, (long long)sB, DX, rows,
+            allow_lds((const void*)k_wgrad2_emb<SRC_BF16>, lds, 1024);
+            hipLaunchKernelGGL(k_wgrad2_emb<SRC_BF16>, grid, dim3(1024), lds, st, s, src, (long long)sT, (long long)sB, DX, rows,
                                nrows, g->embedding_weight, xt, slab, t1);
         }
         if (slab != nullptr)
@@ -1331,9 +1328,9 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
             const int t1 = s.Ncat / W2Cat::BN1;
             size_t lds = 0;
             const int zs = split2(t1, W2Cat::LDS_BYTES, &lds);
-            allow_lds((const void*)k_wgrad2_cat, lds, 512);
+            allow_lds((const void*)k_wgrad2_cat, lds, 1024);
             float* slab = slab_for(t1, zs, wgrad2_tile_floats<W2Cat>());
-            hipLaunchKernelGGL(k_wgrad2_cat, dim3(t1, 1, zs), dim3(512), lds, st, s, DZ, X, rows, nrows, g->rnn_weight_ih[0],
+            hipLaunchKernelGGL(k_wgrad2_cat, dim3(t1, 1, zs), dim3(1024), lds, st, s, DZ, X, rows, nrows, g->rnn_weight_ih[0],
                                g->rnn_weight_ih[1], g->linear_emb_weight, cb, slab);
             if (slab != nullptr) {
                 wo.cb = cb;
@@ -1359,9 +1356,9 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
         const int t1 = s.Gp / W2Hh::BN1, t2 = s.Hp / W2Hh::BN2;
         size_t lds = 0;
         const int zs = split2(2 * t1 * t2, W2Hh::LDS_BYTES, &lds);
-        allow_lds((const void*)k_wgrad2_hh, lds, 512);
+        allow_lds((const void*)k_wgrad2_hh, lds, 1024);
         float* slab = slab_for(2 * t1 * t2, zs, wgrad2_tile_floats<W2Hh>());
-        hipLaunchKernelGGL(k_wgrad2_hh, dim3(t1, t2, 2 * zs), dim3(512), lds, st, s, DZ, Hs, rows, nrows, g->rnn_weight_hh[0],
+        hipLaunchKernelGGL(k_wgrad2_hh, dim3(t1, t2, 2 * zs), dim3(1024), lds, st, s, DZ, Hs, rows, nrows, g->rnn_weight_hh[0],
                            g->rnn_weight_hh[1], slab);
         if (slab != nullptr)
             hipLaunchKernelGGL((k_wgrad2_reduce<W2Hh, W2_HH>), dim3(2 * t1 * t2, 8 * W2Hh::T1 * W2Hh::T2 * 64 / 256), dim3(256), 0, st,

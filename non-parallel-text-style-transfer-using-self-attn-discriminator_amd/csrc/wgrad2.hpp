@@ -62,101 +62,208 @@ __device__ __forceinline__ void lds_read_ints(int (&v)[N], const unsigned (&addr
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
 
-template <int BN1_, int BN2_, int W1_, int W2_, int D_ = 1>
+template <int KIND> struct W2SoftLoad;
+template <> struct W2SoftLoad<SRC_BF16> {
+    static __device__ __forceinline__ u32x4 load(const bf16raw* p) { return *(const u32x4h*)p; }
+};
+template <> struct W2SoftLoad<SRC_F32> {
+    static __device__ __forceinline__ RawF32x8 load(const float* p) {
+        RawF32x8 r;
+        r.lo = *(const f32x4u*)p;
+        r.hi = *(const f32x4u*)(p + 4);
+        return r;
+    }
+};
+
+template <int BN1_, int BN2_, int W1_, int W2_>
 struct W2Cfg {
-    static constexpr int BN1 = BN1_, BN2 = BN2_, W1 = W1_, W2 = W2_, BK = 64, NT = 512;
+    static constexpr int BN1 = BN1_, BN2 = BN2_, W1 = W1_, W2 = W2_, BK = 64;
+    static constexpr int NT = 1024;                                  // 8 compute waves, 4 A-loader waves, 4 B-loader waves
     static constexpr int T1 = BN1_ / W1_ / 16, T2 = BN2_ / W2_ / 16;
     static constexpr int P1 = BN1_ * 2, P2 = BN2_ * 2;               // LDS row pitch (unpadded), bytes
     static constexpr int CPR1 = BN1_ / 8, CPR2 = BN2_ / 8;           // 16-byte chunks per tile row
-    static constexpr int ABYTES = BK * P1, BBYTES = BK * P2, STAGE = ABYTES + BBYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE;                      // + 4 bytes per list position of the workgroup's slice (row indices)
-    static constexpr int NI = CPR2 / 8;                              // LDS-direct instructions (64 chunks each) per wave and stage
-    static constexpr int ACH = BK * CPR1 / NT;                       // register-staged A chunks per thread and stage
-    static constexpr int D = D_;                                     // A register sets (tiles in flight besides the two LDS stages)
+    static constexpr int ABYTES = BK * P1, BBYTES = BK * P2;
+    static constexpr int BOFF = 2 * ABYTES;                          // LDS: A0 A1 B0 B1 B2
+    static constexpr int LDS_BYTES = 2 * ABYTES + 3 * BBYTES;
+    static constexpr int NIB = BBYTES / 1024 / 4;                    // LDS-direct instructions per B-loader wave and tile
+    static constexpr int ACH = BK * CPR1 / 256;                      // A chunks per loader thread and tile
     static constexpr int SW1 = W2Swz<BN1_>::kind, SW2 = W2Swz<BN2_>::kind;
-    static_assert(W1_ * W2_ == 8, "eight waves");
-    static_assert(CPR2 % 8 == 0, "LDS-direct instructions must split evenly over the waves");
+    static_assert(W1_ * W2_ == 8, "eight compute waves");
+    static_assert(BN1_ == 128, "the A loaders map 16 lanes to a tile row");
+    static_assert(BBYTES % 4096 == 0, "LDS-direct instructions must split evenly over the four B-loader waves");
     static_assert(BN1_ % (W1_ * 16) == 0 && BN2_ % (W2_ * 16) == 0, "tile/wave mismatch");
     static_assert((BN1_ / 16) % (SW1 == 0 ? 8 : 4) == 0 && (BN2_ / 16) % (SW2 == 0 ? 8 : 4) == 0, "swizzle groups");
-    static_assert((BK * CPR1) % NT == 0, "A staging must divide evenly");
 };
 
-// The A operand (the long one: DZ resp. the soft tokens S, streamed from HBM once) passes through registers, W::D
-// tiles deep: HBM latency under load is ~2 us and an iteration ~1 us.  (With A on LDS-direct loads as well hipcc put
-// s_waitcnt vmcnt(0) in front of every tile's first barrier, and LDS holds only two stages anyway.)  The B operand
-// (X, dX, Hs: a few 10 MB, L2-resident, re-read by every column tile) goes global -> LDS by LDS-direct loads.
+// Three wave roles, as in K1 (k_softemb_fwd_ws3): the accumulators of a 128 x 320 tile leave a wave that also loads
+// no room for more than one tile of the long operand in flight (two or three register sets spill), and with one tile
+// in flight every k-tile ran at HBM latency (2-3 us per 64-row stage, 285 / 127 / 97 us per launch).  Here
+//   waves 0-7    multiply: transposing fragment reads + MFMAs, no vector-memory instruction until the results;
+//   waves 8-11   A loaders (the long operand: DZ resp. the soft tokens S, streamed from HBM once): register-staged
+//                (dtype conversion, 2-/4-byte aligned rows), D tiles of loads in flight in D static register sets
+//                (loop unrolled D times: hipcc's own counted vmcnt waits), two LDS stages;
+//   waves 12-15  B loaders (X, dX, Hs: a few 10 MB, L2-resident, re-read by every column tile): LDS-direct loads, three
+//                LDS stages, two tiles in flight, own vmcnt counting, raw barriers.
+// One workgroup barrier per tile, 1 + nk barriers in every role.  Token rows come from the compacted row list: a
+// loader lane fetches ONE list entry per tile (a tile ahead in the B loaders, D tiles ahead in the A loaders) and the
+// lanes of a wave exchange them with ds_bpermute (no LDS memory, no memory operand: the waitcnt pass leaves the
+// LDS-direct loads alone).  Entries past the slice are clamped to its last row: B rows stay finite, A rows are zeroed
+// on their way to LDS.
 //
-// a_load(row, col, ok) -> u32x4        8 bf16 of columns [col, col + 8) of the block tile; zeros when !ok; BRANCH-FREE
+// a_load(row, col) -> RAW              8 entries of columns [col, col + 8) of the block tile; BRANCH-FREE
+// cvt(RAW) -> u32x4                    the 8 bf16 that go to LDS
 // b_src(row, col) -> const void*       global address of that 16-byte chunk of B; 16-byte aligned
 // patch(lds_chunk_ptr, col)            called for every B chunk a lane has loaded, once it has landed (ones column)
-// AVM                                  vector-memory instructions of one tile's a_load calls per lane; < 0: not static
 // acc[t1][t2][e]: as in wgrad.hpp (plain operand order: 16 lanes hold 16 consecutive n2 of one row n1)
-template <class W, int AVM, class RO, class AL, class BS, class PB>
-__device__ __forceinline__ void wgrad2_core(int j_begin, int j_end, RO row_of, AL a_load, BS b_src, PB patch,
-                                            f32x4 (&acc)[W::T1][W::T2], unsigned char* lds) {
+// Returns true in the compute waves (which hold the results), false in the loader waves (which are done).
+template <class W, class RAW, int D, class AL, class CV, class BS, class PB>
+__device__ __forceinline__ bool wgrad2_core(const int* __restrict__ list, int j_begin, int j_end, AL a_load, CV cvt, BS b_src,
+                                            PB patch, f32x4 (&acc)[W::T1][W::T2], unsigned char* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int w1 = wave / W::W2, w2 = wave % W::W2;
     const int nk = (j_end - j_begin + W::BK - 1) / W::BK;
-    // ---- static map of this lane's LDS-direct slots: instruction q = wave + 8 i covers chunks 64 q .. 64 q + 63 of the B tile
-    int srow[W::NI], scol[W::NI];
+    if (wave >= 12) {
+        // ------------------------------------- B loader waves ------------------------------------------------------
+        const int ww = wave - 12;
+        // instruction i of this wave covers chunks 64 (NIB ww + i) .. + 63 of the tile (row-major, CPR2 per row):
+        // tile rows 16 ww .. 16 ww + 15
+        int rsel[W::NIB], scol[W::NIB];
 #pragma unroll
-    for (int i = 0; i < W::NI; ++i) {
-        const int g = 64 * (wave + 8 * i) + lane, r = g / W::CPR2, p = g - r * W::CPR2;
-        srow[i] = r;
-        scol[i] = (p ^ (w2_swz<W::SW2>(r) << 1)) * 8;
-    }
-    auto slot_off = [&](int i) { return W::ABYTES + (wave + 8 * i) * 1024; };     // wave-uniform
-    // the slice's row indices, clamped into the list, one int per list position of the nk tiles
-    int* idxl = (int*)(lds + W::LDS_BYTES);
-    for (int i = tid; i < nk * W::BK; i += W::NT) {
-        const int j = j_begin + i;
-        idxl[i] = row_of(j < j_end ? j : j_end - 1);
-    }
-    __syncthreads();
-    auto issue = [&](int st, int kt) {                 // B tile kt -> stage st (rows past the end: a clamped, finite row)
-        unsigned char* base = lds + st * W::STAGE;
-        const unsigned ix = lds_addr(idxl + kt * W::BK);
-        int rowv[W::NI];
-        unsigned ad[W::NI];
-#pragma unroll
-        for (int i = 0; i < W::NI; ++i) ad[i] = ix + 4u * (unsigned)srow[i];
-        lds_read_ints<W::NI>(rowv, ad);
-#pragma unroll
-        for (int i = 0; i < W::NI; ++i)
-            __builtin_amdgcn_global_load_lds((gmem_cv*)b_src(rowv[i], scol[i]), (lds_v*)(base + slot_off(i)), 16, 0, 0);
-    };
-    // register-staged A: chunk g = tid + 512 i -> tile row g / CPR1, column chunk g % CPR1
-    u32x4 ra[W::D][W::ACH];
-    auto a_fetch = [&](auto set, int kt) {             // kt may lie past the last tile: nothing valid, dummy loads
-        constexpr int S = decltype(set)::value;
-        const int ktc = kt < nk ? kt : nk - 1;
-        const int left = kt < nk ? j_end - (j_begin + kt * W::BK) : 0;
-        const unsigned ix = lds_addr(idxl + ktc * W::BK);
-        int rowv[W::ACH];
-        unsigned ad[W::ACH];
-#pragma unroll
-        for (int i = 0; i < W::ACH; ++i) ad[i] = ix + 4u * (unsigned)((tid + i * W::NT) / W::CPR1);
-        lds_read_ints<W::ACH>(rowv, ad);
-#pragma unroll
-        for (int i = 0; i < W::ACH; ++i) {
-            const int g = tid + i * W::NT, r = g / W::CPR1, p = g - r * W::CPR1;
-            ra[S][i] = a_load(rowv[i], p * 8, r < left);
+        for (int i = 0; i < W::NIB; ++i) {
+            const int g = 64 * (W::NIB * ww + i) + lane, r = g / W::CPR2, p = g - r * W::CPR2;
+            rsel[i] = (r - 16 * ww) * 4;
+            scol[i] = (p ^ (w2_swz<W::SW2>(r) << 1)) * 8;
         }
-    };
-    auto a_store = [&](auto set, int st) {
-        constexpr int S = decltype(set)::value;
-        unsigned char* As = lds + st * W::STAGE;
+        // list entries through inline asm: a compiler-tracked load that is pending across the loop's branches gets
+        // s_waitcnt vmcnt(0) in front of its use -- behind the LDS-direct loads of the tile before.  The waits that
+        // cover these loads are the counted ones below; they carry the register so that no use moves above them.
+        auto ldidx = [&](int t) {
+            const int j = j_begin + t * W::BK + 16 * ww + (lane & 15);
+            const int* q = list + (j < j_end ? j : j_end - 1);
+            int v;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+            return v;
+        };
+        auto issue = [&](int st, int xi) {
+            unsigned char* base = lds + W::BOFF + st * W::BBYTES + ww * (W::NIB * 1024);
 #pragma unroll
-        for (int i = 0; i < W::ACH; ++i) {
-            const int g = tid + i * W::NT, r = g / W::CPR1, p = g - r * W::CPR1;
-            *(u32x4*)(As + r * W::P1 + ((p ^ (w2_swz<W::SW1>(r) << 1)) << 4)) = ra[S][i];
+            for (int i = 0; i < W::NIB; ++i) {
+                const int row = __builtin_amdgcn_ds_bpermute(rsel[i], xi);
+                __builtin_amdgcn_global_load_lds((gmem_cv*)b_src(row, scol[i]), (lds_v*)(base + i * 1024), 16, 0, 0);
+            }
+        };
+        auto landed = [&](int st) {                    // B chunks this lane loaded into stage st have landed
+            unsigned char* base = lds + W::BOFF + st * W::BBYTES + ww * (W::NIB * 1024) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < W::NIB; ++i) patch(base + i * 1024, scol[i]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int x0 = ldidx(0), x1 = ldidx(1), xc = ldidx(2);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(xc)::"memory");
+        issue(0, x0);
+        if (nk > 1) {
+            issue(1, x1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W::NIB) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-    };
+        landed(0);
+        __builtin_amdgcn_s_barrier();                  // tile 0 ready
+        int st1 = 1, st2 = 2;                          // stages of tiles kt + 1, kt + 2
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage (kt + 2) % 3 was last read in iteration kt - 1: free
+            if (kt + 2 < nk) {
+                int xn = ldidx(kt + 3);                // BEFORE this tile's LDS-direct loads: vmcnt retires in order
+                issue(st2, xc);
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn) : "n"(W::NIB) : "memory");   // tile kt + 1 (and xn) has landed
+                xc = xn;
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (kt + 1 < nk) landed(st1);
+            st1 = st1 == 2 ? 0 : st1 + 1;
+            st2 = st2 == 2 ? 0 : st2 + 1;
+            __builtin_amdgcn_s_barrier();
+        }
+        return false;
+    }
+    if (wave >= 8) {
+        // ------------------------------------- A loader waves ------------------------------------------------------
+        const int w = wave - 8, q4 = lane >> 4, pc = lane & 15;
+        // chunk i of this lane: tile row 16 i + 4 w + q4, column chunk pc; the lane FETCHES the list entry of tile row
+        // 16 ((lane >> 2) & 3) + 4 w + (lane & 3), so chunk i's entry sits in lane 4 i + q4 of the wave
+        const int ridx = 16 * ((lane >> 2) & 3) + 4 * w + (lane & 3);
+        auto ldidx = [&](int t) {
+            const int j = j_begin + t * W::BK + ridx;
+            return list[j < j_end ? j : j_end - 1];
+        };
+        RAW ra[D][W::ACH];
+        int xi[D];
+        // Rows past the end of the slice are loaded like any other (their list entry is clamped: a valid row) and
+        // zeroed on the way to LDS.  (Zeroed right after the load, the select is a USE of the loaded value: hipcc put
+        // the selects of all register sets at the end of the unrolled loop body, and the wait in front of them
+        // drained every load in flight once per D tiles.)
+        auto load_tile = [&](auto par) {
+            constexpr int P = decltype(par)::value;
+#pragma unroll
+            for (int i = 0; i < W::ACH; ++i) {
+                const int row = __builtin_amdgcn_ds_bpermute((4 * i + q4) * 4, xi[P]);
+                ra[P][i] = a_load(row, pc * 8);
+            }
+        };
+        auto to_lds = [&](auto par, int t) {
+            constexpr int P = decltype(par)::value;
+            unsigned char* As = lds + (t & 1) * W::ABYTES;
+            const int left = j_end - (j_begin + t * W::BK);
+#pragma unroll
+            for (int i = 0; i < W::ACH; ++i) {
+                const int r = 16 * i + 4 * w + q4;
+                const u32x4 v = cvt(ra[P][i]);
+                *(u32x4*)(As + r * W::P1 + ((pc ^ (w2_swz<W::SW1>(r) << 1)) << 4)) = r < left ? v : u32x4{0u, 0u, 0u, 0u};
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        static_for<D>([&](auto d) { xi[decltype(d)::value] = ldidx(decltype(d)::value); });
+        static_for<D>([&](auto d) {
+            load_tile(d);
+            xi[decltype(d)::value] = ldidx(decltype(d)::value + D);
+        });
+        to_lds(S0{}, 0);
+        load_tile(S0{});
+        xi[0] = ldidx(2 * D);
+        __syncthreads();                               // tile 0 ready
+        // steady state, branch-free: iteration j writes tile j + 1 (set (j + 1) % D), requests tile j + 1 + D into the
+        // same set and that set's list entries of tile j + 1 + 2 D
+        int kt = 0;
+        for (; kt + D < nk; kt += D) {
+            static_for<D>([&](auto u) {
+                constexpr int U = decltype(u)::value;
+                using P = std::integral_constant<int, (U + 1) % D>;
+                to_lds(P{}, kt + U + 1);
+                load_tile(P{});
+                xi[P::value] = ldidx(kt + U + 1 + 2 * D);
+                __syncthreads();
+            });
+        }
+        for (int j = kt; j < nk; ++j) {                // the last tiles: everything they need has been requested
+            if (j + 1 < nk) {
+                static_for<D>([&](auto d) {
+                    if ((j + 1) % D == decltype(d)::value) to_lds(d, j + 1);
+                });
+            }
+            __syncthreads();
+        }
+        return false;
+    }
+    // ----------------------------------------- compute waves ------------------------------------------------------
+    const int w1 = wave / W::W2, w2 = wave % W::W2;
     const int rowsel = 4 * (lane >> 4) + ((lane >> 2) & 3), p4 = (lane & 3) * 4;
     const int s1 = w2_swz<W::SW1>(rowsel), s2 = w2_swz<W::SW2>(rowsel);
-    auto mfma_stage = [&](int st) {
-        const unsigned char* As = lds + st * W::STAGE + rowsel * W::P1 + p4 * 2;
-        const unsigned char* Bs = lds + st * W::STAGE + W::ABYTES + rowsel * W::P2 + p4 * 2;
+    __syncthreads();                                   // tile 0 ready
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* As = lds + (kt & 1) * W::ABYTES + rowsel * W::P1 + p4 * 2;
+        const unsigned char* Bs = lds + W::BOFF + st * W::BBYTES + rowsel * W::P2 + p4 * 2;
+        st = st == 2 ? 0 : st + 1;
 #pragma unroll
         for (int ks = 0; ks < W::BK / 32; ++ks) {
             bf16x8 fa[W::T1];
@@ -171,81 +278,9 @@ __device__ __forceinline__ void wgrad2_core(int j_begin, int j_end, RO row_of, A
                     acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t1], fb, acc[t1][t2], 0, 0, 0);
             }
         }
-    };
-    auto patch_landed = [&](int st) {                  // B chunks this lane loaded into stage st have landed
-        unsigned char* base = lds + st * W::STAGE;
-#pragma unroll
-        for (int i = 0; i < W::NI; ++i) patch(base + slot_off(i) + lane * 16, scol[i]);
-    };
-    // Vector-memory operations of a wave in issue order (steady state): ... | Afetch(k+3) DMA_B(k+1) | Afetch(k+4) DMA_B(k+2) | ...
-    // At the top of iteration k tile k's B has landed once at most what the end of iteration k-1 issued (AVM + NI
-    // operations) is outstanding; its A chunks were written to LDS before that.  AVM < 0 (element-guarded loads, no
-    // static count): wait for everything.
-    constexpr int ALLOW = W::NI + (AVM > 0 ? AVM : 0) * W::D;
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-
-    int k = 0;
-    if constexpr (W::D == 2) {
-        // ---- two register sets (tiles k + 2, k + 3 in flight), loop unrolled by two so each set is static.  Only
-        // the configurations whose accumulators leave room use it (hipcc spills the 80-register tiles).
-        a_fetch(S0{}, 0);
-        a_fetch(S1{}, 1);
-        a_store(S0{}, 0);
-        issue(0, 0);
-        a_store(S1{}, 1);
-        if (nk > 1) issue(1, 1);
-        a_fetch(S0{}, 2);
-        a_fetch(S1{}, 3);
-        // iteration k (k + 2 < nk): multiply tile k; then tile k + 2 (set k % 2) -> the stage just freed, that set
-        // refilled with tile k + 4.  No branch inside: hipcc keeps counted vmcnt waits for the register sets.
-        auto body = [&](auto set, int kk) {
-            const int st = decltype(set)::value;       // kk & 1
-            if constexpr (AVM >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            patch_landed(st);
-            __syncthreads();
-            mfma_stage(st);
-            __syncthreads();                           // stage st consumed by every wave
-            a_store(set, st);
-            issue(st, kk + 2);                         // B first: vmcnt retires in order, so the wait for B(k) at
-            a_fetch(set, kk + 4);                      // the top of iteration k must not cover A(k + 2)
-        };
-        while (true) {
-            if (!(k + 2 < nk)) break;
-            body(S0{}, k++);
-            if (!(k + 2 < nk)) break;
-            body(S1{}, k++);
-        }
-    } else {
-        // ---- one register set: tile k + 2 is in flight while tile k is multiplied
-        a_fetch(S0{}, 0);
-        a_store(S0{}, 0);
-        issue(0, 0);
-        a_fetch(S0{}, 1);
-        a_store(S0{}, 1);
-        a_fetch(S0{}, 2);
-        if (nk > 1) issue(1, 1);
-        for (; k + 2 < nk; ++k) {
-            const int st = k & 1;
-            if constexpr (AVM >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            patch_landed(st);
-            __syncthreads();
-            mfma_stage(st);
-            __syncthreads();                           // stage st consumed by every wave
-            a_store(S0{}, st);
-            a_fetch(S0{}, k + 3);
-            issue(st, k + 2);
-        }
+        __syncthreads();                               // tile kt consumed; tile kt + 1 written by the loaders
     }
-    for (; k < nk; ++k) {                              // the last two tiles: nothing left to issue
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        patch_landed(k & 1);
-        __syncthreads();
-        mfma_stage(k & 1);
-        __syncthreads();
-    }
+    return true;
 }
 
 template <class W, class Epi>
@@ -290,6 +325,11 @@ __device__ __forceinline__ void wgrad2_to_slab(const f32x4 (&acc)[W::T1][W::T2],
 template <class W>
 __host__ __device__ constexpr long long wgrad2_tile_floats() { return (long long)W::BN1 * W::BN2; }
 
+// d embedding.weight: the vocabulary tile (128 columns) that holds the ragged end of V starts at V - 128 instead
+// (V >= 128): every load is a whole in-row chunk, and the rows it shares with the tile before are dropped when the
+// results are written.
+__host__ __device__ __forceinline__ int w2_emb_first(int tile, int V) { return tile * 128 + 128 <= V ? tile * 128 : V - 128; }
+
 enum { W2_EMB = 0, W2_CAT = 1, W2_HH = 2 };
 struct W2Out {
     float* gemb;
@@ -328,7 +368,8 @@ __global__ __launch_bounds__(256) void k_wgrad2_reduce(Shape s, const float* __r
         const int n1 = n1t * W::BN1 + w1 * (W::BN1 / W::W1) + 16 * t1 + 4 * (lane >> 4) + e;
         const float x = v[e];
         if (KIND == W2_EMB) {
-            if (n1 < s.V && n2 < s.E) o.gemb[(long long)n1 * s.E + n2] += x;
+            const int n1s = n1 - n1t * W::BN1 + w2_emb_first(n1t, s.V);      // the last tile starts at V - 128
+            if (n1s >= n1t * W::BN1 && n1s < s.V && n2 < s.E) o.gemb[(long long)n1s * s.E + n2] += x;
         } else if (KIND == W2_HH) {
             float* g = dir ? o.ghh1 : o.ghh0;
             const int row = gate_row(n1, s.H);
@@ -368,7 +409,7 @@ __global__ __launch_bounds__(256) void k_wgrad2_reduce(Shape s, const float* __r
 // grid: (Ncat / 128, 1, row splits)
 // ------------------------------------------------------------------------------------------------
 typedef W2Cfg<128, 320, 2, 4> W2Cat;
-__global__ __launch_bounds__(512) void k_wgrad2_cat(Shape s, const bf16raw* __restrict__ DZ, const bf16raw* __restrict__ X,
+__global__ __launch_bounds__(1024) void k_wgrad2_cat(Shape s, const bf16raw* __restrict__ DZ, const bf16raw* __restrict__ X,
                                                    const int* __restrict__ rows, const int* __restrict__ nrows,
                                                    float* __restrict__ gih0, float* __restrict__ gih1,
                                                    float* __restrict__ glin, CatBias cb, float* __restrict__ slab) {
@@ -391,15 +432,16 @@ __global__ __launch_bounds__(512) void k_wgrad2_cat(Shape s, const bf16raw* __re
     const int ecol = ones && s.E < Ep ? s.E : -1;
     f32x4 acc[W::T1][W::T2];
     wgrad2_zero<W>(acc);
-    wgrad2_core<W, W::ACH>(
-        j_begin, j_end, [&](int j) { return rows[j]; },
-        [&](int m, int c, bool ok) { return load16_if(DZ + (long long)m * Ncat + n10 + c, DZ, ok); },
+    if (!wgrad2_core<W, u32x4, 4>(
+        rows, j_begin, j_end,
+        [&](int m, int c) { return *(const u32x4*)(DZ + (long long)m * Ncat + n10 + c); }, Ident(),
         [&](int m, int c) { return (const void*)(X + (long long)m * Ep + c); },
         [&](unsigned char* chunk, int c) {
             // X's padding column E carries a 1 in every row: dWcat's column E is the column sum of DZ
             if (ecol >= c && ecol < c + 8) lds_store16b(chunk + (ecol - c) * 2, 0x3f80u);
         },
-        acc, wg_lds);
+        acc, wg_lds))
+        return;
     if (slab != nullptr) {
         wgrad2_to_slab<W>(acc, slab, (long long)blockIdx.z * gridDim.x + blockIdx.x);
         return;
@@ -439,8 +481,8 @@ __global__ __launch_bounds__(512) void k_wgrad2_cat(Shape s, const bf16raw* __re
 // dWhh[d] = sum_t dZ_t[d]^T . h_prev(t)[d]  (see k_wgrad_hh).  Gp % 128 == 0, Hp % 256 == 0.
 // grid: (Gp / 128, Hp / 256, 2 * row splits)
 // ------------------------------------------------------------------------------------------------
-typedef W2Cfg<128, 256, 2, 4, 2> W2Hh;
-__global__ __launch_bounds__(512) void k_wgrad2_hh(Shape s, const bf16raw* __restrict__ DZ, const bf16raw* __restrict__ Hs,
+typedef W2Cfg<128, 256, 2, 4> W2Hh;
+__global__ __launch_bounds__(1024) void k_wgrad2_hh(Shape s, const bf16raw* __restrict__ DZ, const bf16raw* __restrict__ Hs,
                                                   const int* __restrict__ rows, const int* __restrict__ nrows,
                                                   float* __restrict__ ghh0, float* __restrict__ ghh1, float* __restrict__ slab) {
     typedef W2Hh W;
@@ -456,11 +498,12 @@ __global__ __launch_bounds__(512) void k_wgrad2_hh(Shape s, const bf16raw* __res
     const long long shift = dir ? s.B : -s.B;         // token-row offset of the previous recurrence step
     f32x4 acc[W::T1][W::T2];
     wgrad2_zero<W>(acc);
-    wgrad2_core<W, W::ACH>(
-        j_begin, j_end, [&](int j) { return list[j]; },
-        [&](int m, int c, bool ok) { return load16_if(DZ + (long long)m * Ncat + dir * Gp + n10 + c, DZ, ok); },
+    if (!wgrad2_core<W, u32x4, 4>(
+        list, j_begin, j_end,
+        [&](int m, int c) { return *(const u32x4*)(DZ + (long long)m * Ncat + dir * Gp + n10 + c); }, Ident(),
         [&](int m, int c) { return (const void*)(Hs + ((m + shift) * 2 + dir) * Hp + n20 + c); },
-        [](unsigned char*, int) {}, acc, wg_lds);
+        [](unsigned char*, int) {}, acc, wg_lds))
+        return;
     if (slab != nullptr) {
         const long long tile = ((long long)dir * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y;
         wgrad2_to_slab<W>(acc, slab, (long long)(blockIdx.z >> 1) * (2 * gridDim.x * gridDim.y) + tile);
@@ -481,10 +524,10 @@ __global__ __launch_bounds__(512) void k_wgrad2_hh(Shape s, const bf16raw* __res
 // ------------------------------------------------------------------------------------------------
 typedef W2Cfg<128, 320, 2, 4> W2Emb;
 template <int KIND>
-__global__ __launch_bounds__(512) void k_wgrad2_emb(Shape s, const void* __restrict__ src, long long sT, long long sB,
-                                                   const bf16raw* __restrict__ DX, const int* __restrict__ rows,
-                                                   const int* __restrict__ nrows, float* __restrict__ gemb, int xcd_tiles,
-                                                   float* __restrict__ slab, int ntiles) {
+__global__ __launch_bounds__(1024) void k_wgrad2_emb(Shape s, const void* __restrict__ src, long long sT, long long sB,
+                                                    const bf16raw* __restrict__ DX, const int* __restrict__ rows,
+                                                    const int* __restrict__ nrows, float* __restrict__ gemb, int xcd_tiles,
+                                                    float* __restrict__ slab, int ntiles) {
     typedef W2Emb W;
     typedef SoftRow<KIND> SR;
     typedef typename SR::Elem Elem;
@@ -492,31 +535,22 @@ __global__ __launch_bounds__(512) void k_wgrad2_emb(Shape s, const void* __restr
     // workgroups b, b + 8, ... share an XCD and take NEIGHBOURING vocabulary tiles (see k_wgrad_emb)
     const int tile1 = (int)(blockIdx.x & 7) * xcd_tiles + (int)(blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= xcd_tiles) return;
-    const int n10 = tile1 * W::BN1;
-    if (n10 >= s.V) return;
+    if (tile1 * W::BN1 >= s.V) return;
+    const int n10 = w2_emb_first(tile1, s.V);
     int j_begin, j_end;
     if (!wgrad_slice(nrows[ROWS_ANY], blockIdx.z, gridDim.z, &j_begin, &j_end)) return;
     const int V = s.V, Ep = s.Ep, B = s.B;
     f32x4 acc[W::T1][W::T2];
     wgrad2_zero<W>(acc);
-    auto s_row = [&](int m, bool ok) -> const Elem* {
-        const int t = m / B, b = m - t * B;
-        return ok ? (const Elem*)src + (long long)t * sT + (long long)b * sB : nullptr;
-    };
-    auto row_of = [&](int j) { return rows[j]; };
-    auto b_src = [&](int m, int c) { return (const void*)(DX + (long long)m * Ep + c); };
-    auto none = [](unsigned char*, int) {};
-    if (n10 + W::BN1 <= V) {     // interior vocabulary tile: whole chunks, branch-free loads
-        wgrad2_core<W, W::ACH * (KIND == SRC_F32 ? 2 : 1)>(
-            j_begin, j_end, row_of,
-            [&](int m, int c, bool ok) { return typename SR::Cvt()(SR::load_fast(s_row(m, ok), (const Elem*)src, n10 + c)); },
-            b_src, none, acc, wg_lds);
-    } else {                     // the tile holding the ragged end of V: element-guarded loads
-        wgrad2_core<W, -1>(
-            j_begin, j_end, row_of,
-            [&](int m, int c, bool ok) { return typename SR::Cvt()(SR::load(s_row(m, ok), n10 + c, V)); }, b_src, none, acc,
-            wg_lds);
-    }
+    if (!wgrad2_core<W, typename SR::Raw, (sizeof(typename SR::Raw) > 16 ? 2 : 4)>(
+        rows, j_begin, j_end,
+        [&](int m, int c) {
+            const int t = m / B, b = m - t * B;
+            return W2SoftLoad<KIND>::load((const Elem*)src + (long long)t * sT + (long long)b * sB + n10 + c);
+        },
+        typename SR::Cvt(), [&](int m, int c) { return (const void*)(DX + (long long)m * Ep + c); },
+        [](unsigned char*, int) {}, acc, wg_lds))
+        return;
     if (slab != nullptr) {
         wgrad2_to_slab<W>(acc, slab, (long long)blockIdx.z * ntiles + tile1);
         return;
@@ -524,7 +558,7 @@ __global__ __launch_bounds__(512) void k_wgrad2_emb(Shape s, const void* __restr
     const int E = s.E;
     wgrad2_epilogue<W>(acc, [&](int r1, int n2, float v) {
         const int n1 = n10 + r1;
-        if (n1 < V && n2 < E) unsafeAtomicAdd(gemb + (long long)n1 * E + n2, v);
+        if (n1 >= tile1 * W::BN1 && n1 < V && n2 < E) unsafeAtomicAdd(gemb + (long long)n1 * E + n2, v);
     });
 }
 

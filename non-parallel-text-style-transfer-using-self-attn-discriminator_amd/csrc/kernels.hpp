@@ -99,6 +99,15 @@ struct SoftRow<SRC_F32> {
         if (p == nullptr) r.lo = r.hi = f32x4{0.f, 0.f, 0.f, 0.f};
         return r;
     }
+    // unconditional load; the caller zeroes invalid rows when it USES the value (a select right after the load is a
+    // use: in a loop unrolled over register sets hipcc collects such selects at the end of the body and drains every
+    // load in flight in front of them)
+    static __device__ __forceinline__ Raw load_raw(const float* q) {
+        Raw r;
+        r.lo = *(const f32x4u*)q;
+        r.hi = *(const f32x4u*)(q + 4);
+        return r;
+    }
     static __device__ __forceinline__ Raw load(const float* p, int k, int V) {
         Raw r;
         if (p != nullptr && k + 8 <= V) {
@@ -123,6 +132,7 @@ struct SoftRow<SRC_BF16> {
         const u32x4 v = *(const u32x4h*)(p != nullptr ? p + k : dummy);
         return p != nullptr ? v : u32x4{0u, 0u, 0u, 0u};
     }
+    static __device__ __forceinline__ Raw load_raw(const bf16raw* q) { return *(const u32x4h*)q; }
     static __device__ __forceinline__ Raw load(const bf16raw* p, int k, int V) {
         if (p != nullptr && k + 8 <= V) return *(const u32x4h*)(p + k);
         unsigned t[8];
@@ -315,19 +325,24 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_ws3(Shape s, const void* _
         }
         const int aoff0 = lds_off<C>(r0, c0) * 2;              // row + 32 i keeps the swizzle: + i * 4096 bytes
         typename SR::Raw ra[D][4];
-        const Elem* dummy = (const Elem*)src;
+        const Elem* aeff[4];                                   // rows nobody needs load row 0 and are zeroed in to_lds
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aeff[i] = arow[i] != nullptr ? arow[i] : (const Elem*)src;
         const int nkf = V / 64;                                // whole k-tiles: unguarded, branch-free loads
         auto load_tile = [&](auto par, int kt) {               // clamped, never skipped: static operation counts
             constexpr int P = decltype(par)::value;
             const int k0 = (kt < nkf ? kt : nkf - 1) * 64;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_fast(arow[i], dummy, k0);
+            for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_raw(aeff[i] + k0);
         };
         auto to_lds = [&](auto par, int kt) {
             constexpr int P = decltype(par)::value;
             unsigned char* buf = fw_lds + (kt & 1) * ABYTES;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *(u32x4*)&buf[aoff0 + i * 4096] = typename SR::Cvt()(ra[P][i]);
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = typename SR::Cvt()(ra[P][i]);
+                *(u32x4*)&buf[aoff0 + i * 4096] = arow[i] != nullptr ? v : u32x4{0u, 0u, 0u, 0u};
+            }
         };
         auto tail_to_lds = [&](int kt) {                       // the ragged last k-tile: element-guarded loads
             unsigned char* buf = fw_lds + (kt & 1) * ABYTES;
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_ws3(Shape s, const void* _
                 load_tile(P{}, kt + U + 1 + D);
                 K1P_T(2)
                 __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);             // keeps the next tile's zeroing selects (uses of loads in flight) below
                 K1P_T(3)
                 K1P_ACC
             });
@@ -588,20 +604,25 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
             }
             const int aoff0 = lds_off<C>(r0, c0) * 2;          // row + 32 i keeps the swizzle: + i * 4096 bytes
             typename SR::Raw ra[D][4];
-            const Elem* dummy = (const Elem*)src;
+            const Elem* aeff[4];                               // rows nobody needs load row 0 and are zeroed in to_lds
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aeff[i] = arow[i] != nullptr ? arow[i] : (const Elem*)src;
             // whole k-tiles of this segment: relative j < nw (absolute ka + j < nkf); loads are clamped to them
             const int nw = (nkf < kb ? nkf : kb) - ka;         // may be <= 0: the segment is the ragged tile alone
             auto load_tile = [&](auto par, int j) {
                 constexpr int P = decltype(par)::value;
                 const int k0 = (ka + (j < nw ? j : nw - 1)) * 64;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_fast(arow[i], dummy, k0);
+                for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_raw(aeff[i] + k0);
             };
             auto to_lds = [&](auto par, int j) {
                 constexpr int P = decltype(par)::value;
                 unsigned char* buf = fw_lds + (j & 1) * ABYTES;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *(u32x4*)&buf[aoff0 + i * 4096] = typename SR::Cvt()(ra[P][i]);
+                for (int i = 0; i < 4; ++i) {
+                    const u32x4 v = typename SR::Cvt()(ra[P][i]);
+                    *(u32x4*)&buf[aoff0 + i * 4096] = arow[i] != nullptr ? v : u32x4{0u, 0u, 0u, 0u};
+                }
             };
             auto tail_to_lds = [&](int j) {                    // the ragged last k-tile: element-guarded loads
                 unsigned char* buf = fw_lds + (j & 1) * ABYTES;
@@ -630,6 +651,7 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
                     load_tile(P{}, j + U + 1 + D);
                     K1P_T(2)
                     __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);         // keeps the next tile's zeroing selects (uses of loads in flight) below
                     K1P_T(3)
                     K1P_ACC
                 });

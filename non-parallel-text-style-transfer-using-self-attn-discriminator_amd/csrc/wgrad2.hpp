@@ -62,19 +62,6 @@ __device__ __forceinline__ void lds_read_ints(int (&v)[N], const unsigned (&addr
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
 
-template <int KIND> struct W2SoftLoad;
-template <> struct W2SoftLoad<SRC_BF16> {
-    static __device__ __forceinline__ u32x4 load(const bf16raw* p) { return *(const u32x4h*)p; }
-};
-template <> struct W2SoftLoad<SRC_F32> {
-    static __device__ __forceinline__ RawF32x8 load(const float* p) {
-        RawF32x8 r;
-        r.lo = *(const f32x4u*)p;
-        r.hi = *(const f32x4u*)(p + 4);
-        return r;
-    }
-};
-
 template <int BN1_, int BN2_, int W1_, int W2_>
 struct W2Cfg {
     static constexpr int BN1 = BN1_, BN2 = BN2_, W1 = W1_, W2 = W2_, BK = 64;
@@ -242,6 +229,7 @@ __device__ __forceinline__ bool wgrad2_core(const int* __restrict__ list, int j_
                 load_tile(P{});
                 xi[P::value] = ldidx(kt + U + 1 + 2 * D);
                 __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);     // keeps the next tile's selects (uses of loads in flight) below
             });
         }
         for (int j = kt; j < nk; ++j) {                // the last tiles: everything they need has been requested
@@ -546,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_wgrad2_emb(Shape s, const void* __rest
         rows, j_begin, j_end,
         [&](int m, int c) {
             const int t = m / B, b = m - t * B;
-            return W2SoftLoad<KIND>::load((const Elem*)src + (long long)t * sT + (long long)b * sB + n10 + c);
+            return SR::load_raw((const Elem*)src + (long long)t * sT + (long long)b * sB + n10 + c);
         },
         typename SR::Cvt(), [&](int m, int c) { return (const void*)(DX + (long long)m * Ep + c); },
         [](unsigned char*, int) {}, acc, wg_lds))

@@ -299,13 +299,17 @@ class CNNClassifier(nn.Module):
         else:
             embedded = self.embedding(src)
         embedded = self.dropout_layer(embedded)
-        outputs = []
-        for i, cnn in enumerate(self.cnns):
-            if self.kernel_sizes[i] <= embedded.shape[1]:
-                temp = torch.relu(cnn(embedded.unsqueeze(1)).squeeze(3))
-                temp = torch.nn.functional.max_pool1d(temp, temp.size(2)).squeeze(2)
-            else:
-                temp = torch.zeros(embedded.shape[0], self.num_kernels_each_size, device=embedded.device,
-                                   dtype=embedded.dtype)
-            outputs.append(temp)
-        return self.ffn(torch.cat(outputs, dim=1))
+        return self.ffn(self._pooled_features(embedded))
+
+    def _pooled_features(self, embedded):
+        """[B, T, E] -> [B, len(kernel_sizes) * num_kernels_each_size]: per window size the strongest response of
+        every filter over the sentence (the reference's relu -> max_pool1d over all positions, classifier/models.py:
+        58-70, written as ONE reduction: relu is monotone, so max_t relu(y_t) == relu(max_t y_t)); a window longer
+        than the sentence leaves its block of features at zero, as there."""
+        B, T = embedded.shape[0], embedded.shape[1]
+        feats = embedded.new_zeros((B, len(self.cnns), self.num_kernels_each_size))
+        image = embedded.unsqueeze(1)                                      # one input channel
+        for slot, (width, conv) in enumerate(zip(self.kernel_sizes, self.cnns)):
+            if width <= T:
+                feats[:, slot] = torch.relu(conv(image).squeeze(3).amax(dim=2))
+        return feats.flatten(1)

@@ -32,6 +32,43 @@ __global__ __launch_bounds__(512) void k_rows(u16* __restrict__ p, int M, int V,
     if (!STORE && acc == 0x12345u) *sink = acc;
 }
 
+// Row-tile sweep: the 32 workgroups of an XCD (blockIdx = xcd + 8 * slot) share ONE 256-row tile at a time and cut its
+// columns into 32 strips; the XCD's tiles are xcd, xcd + 8, ...  At any moment the device writes 8 row tiles = 8
+// contiguous 4.8 MB regions instead of a few hundred bytes of every row of the matrix.  SUB = rows of the tile a
+// workgroup writes before moving to the next column tile of 64 (256: the K1' tile order; smaller: not used).
+template <int RPW>
+__global__ __launch_bounds__(512) void k_sweep(u16* __restrict__ p, int M, int V, long long pitch, int strips) {
+    constexpr int LPR = 64 / RPW;
+    constexpr int CW = LPR * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cper = ((V + strips - 1) / strips + 7) / 8 * 8;
+    const int c0 = slot * cper, c1 = min(V, c0 + cper);
+    const int r = lane / LPR, cl = (lane % LPR) * 8;
+    const int tiles = (M + 255) / 256;
+    for (int rt = xcd; rt < tiles; rt += 8) {
+        const int m0 = rt * 256 + wave * 32;
+        for (int c = c0; c < c1; c += CW) {
+#pragma unroll
+            for (int rr = 0; rr < 32; rr += RPW) {
+                const int m = m0 + rr + r, col = c + cl;
+                if (m < M && col + 8 <= c1) *(u32x4h*)(p + (long long)m * pitch + col) = u32x4h{(unsigned)m, (unsigned)col, 1u, 2u};
+            }
+        }
+    }
+}
+template <int RPW>
+float run_sweep(u16* p, int M, int V, long long pitch, int strips) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) k_sweep<RPW><<<8 * strips, 512>>>(p, M, V, pitch, strips);
+    hipEventRecord(a);
+    const int it = 20;
+    for (int i = 0; i < it; ++i) k_sweep<RPW><<<8 * strips, 512>>>(p, M, V, pitch, strips);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / it * 1000.f;
+}
+
 template <int RPW, bool STORE>
 float run(u16* p, int M, int V, long long pitch, int csplit, unsigned* sink) {
     dim3 grid((M + 255) / 256, csplit);
@@ -50,6 +87,16 @@ int main() {
     u16* p; unsigned* sink;
     hipMalloc(&p, (size_t)M * 9408 * 2 + 4096); hipMalloc(&sink, 4);
     hipMemset(p, 0, (size_t)M * 9408 * 2);
+    {
+        const double gb = (double)M * 9353 * 2 / 1e9;
+        for (int strips = 8; strips <= 64; strips *= 2) {
+            float t;
+#define SW(RPW) t = run_sweep<RPW>(p, M, 9353, 9353, strips); \
+            printf("sweep V=9353 strips/XCD=%2d store rows/wave-instr=%2d (%4d B/row): %7.1f us %7.0f GB/s\n", strips, RPW, 64 / RPW * 16, t, gb / t * 1e6);
+            SW(8) SW(4) SW(2) SW(1)
+        }
+    }
+    if (getenv("SWEEP_ONLY")) return 0;
     const int Vs[3] = {9353, 9352, 9344};
     for (int vi = 0; vi < 3; ++vi) {
         const int V = Vs[vi];

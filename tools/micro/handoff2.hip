@@ -220,8 +220,5 @@ int main() {
     // 128 sentences per group (16 workgroups of 128 gate columns), two chains of 64
     line(16, 64, 2, 64, 4, 1);
     line(16, 64, 2, 0, 0, 0);
-    // BPTT: dZ of a chain = 32 sentences x 2048 gate columns bf16 = 128 KB; 64 units per workgroup, 256 MFMAs per chain-step
-    line(8, 128, 1, 0, 0, 0);
-    line(8, 128, 1, 256, 8, 1);
     return 0;
 }

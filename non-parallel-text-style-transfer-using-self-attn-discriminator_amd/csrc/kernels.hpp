@@ -509,6 +509,12 @@ __global__ __launch_bounds__(1024) void k_tile_list(int M, const unsigned char* 
     if (tid == 0) tiles[0] = base;
 }
 
+// Timing-only ablations of the stream-K kernel's roles (tools/k1abl.py builds variant libraries with -DSAD_K1_ABL=<bits>;
+// results are garbage): 1 compute waves skip the MFMAs, 2 ... and their LDS fragment reads, 4 S loaders skip the global
+// loads, 8 ... and the LDS writes, 16 W loaders skip the LDS-direct loads.
+#ifndef SAD_K1_ABL
+#define SAD_K1_ABL 0
+#endif
 template <int KIND>
 __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __restrict__ src, long long sT, long long sB,
                                                        const unsigned char* __restrict__ need, const int* __restrict__ tiles,
@@ -545,6 +551,7 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
             const bf16raw* bo = wembT + (long long)(ww * 80 + 8 + r) * Vp + ((sl ^ (4 + (r >> 1))) << 3) + ka * 64;
             const long long step2 = 16ll * Vp;
             auto issue = [&](int j, int st) {
+                if (SAD_K1_ABL & 16) return;
                 unsigned char* dst = fw_lds + BOFF + st * BBYTES + ww * (80 * 128);
                 const int k0 = j * 64;
 #pragma unroll
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
             }
             const int aoff0 = lds_off<C>(r0, c0) * 2;          // row + 32 i keeps the swizzle: + i * 4096 bytes
             typename SR::Raw ra[D][4];
+            if (SAD_K1_ABL & 4) memset(ra, 0, sizeof(ra));
             const Elem* aeff[4];                               // rows nobody needs load row 0 and are zeroed in to_lds
 #pragma unroll
             for (int i = 0; i < 4; ++i) aeff[i] = arow[i] != nullptr ? arow[i] : (const Elem*)src;
@@ -611,12 +619,14 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
             const int nw = (nkf < kb ? nkf : kb) - ka;         // may be <= 0: the segment is the ragged tile alone
             auto load_tile = [&](auto par, int j) {
                 constexpr int P = decltype(par)::value;
+                if (SAD_K1_ABL & 4) return;
                 const int k0 = (ka + (j < nw ? j : nw - 1)) * 64;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ra[P][i] = SR::load_raw(aeff[i] + k0);
             };
             auto to_lds = [&](auto par, int j) {
                 constexpr int P = decltype(par)::value;
+                if (SAD_K1_ABL & 8) return;
                 unsigned char* buf = fw_lds + (j & 1) * ABYTES;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -689,7 +699,7 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
             const bf16raw* Bs = (const bf16raw*)(fw_lds + BOFF + st * BBYTES);
             st = st == 2 ? 0 : st + 1;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < ((SAD_K1_ABL & 2) ? 0 : 2); ++kk) {
                 bf16x8 af[C::TM], bfr[C::TN];
                 const int ch = kk * 4 + (lane >> 4);
 #pragma unroll
@@ -697,6 +707,13 @@ __global__ __launch_bounds__(1024) void k_softemb_fwd_sk(Shape s, const void* __
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn)
                     bfr[tn] = *(const bf16x8*)&Bs[lds_off<C>(wn * (C::BN / C::WN) + tn * 16 + (lane & 15), ch)];
+                if (SAD_K1_ABL & 1) {
+#pragma unroll
+                    for (int tm = 0; tm < C::TM; ++tm) asm volatile("" ::"v"(af[tm]));
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn) asm volatile("" ::"v"(bfr[tn]));
+                    continue;
+                }
 #pragma unroll
                 for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll

@@ -360,6 +360,8 @@ int sad_soft_finalize(int32_t B, int32_t T, int32_t V, int32_t steps, int32_t ov
 #define SAD_DBG_WITHHOLD_FWD 2
 #define SAD_DBG_WITHHOLD_BWD 3
 #define SAD_DBG_WITHHOLD_UPPER_ONLY 4 /* 1: the two settings above act only on RNN layers above the first */
+#define SAD_DBG_WGRAD_ATOMICS 5 /* 1: the large weight-gradient kernels add their partial tiles with fp32 atomics (the
+                                  * fallback for launches whose partial tiles do not fit the slab) instead of slab + reduce */
 int sad_debug_set(int32_t key, int64_t value);
 
 #ifdef __cplusplus

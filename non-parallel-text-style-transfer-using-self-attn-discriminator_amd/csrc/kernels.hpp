@@ -132,7 +132,7 @@ struct SoftRow<SRC_BF16> {
         const u32x4 v = *(const u32x4h*)(p != nullptr ? p + k : dummy);
         return p != nullptr ? v : u32x4{0u, 0u, 0u, 0u};
     }
-    static __device__ __forceinline__ Raw load_raw(const bf16raw* q) { return *(const u32x4h*)q; }
+    static __device__ __forceinline__ Raw load_raw(const bf16raw* q) { return *(const u32x4h*)q; }   // (non-temporal: K1 166 -> 182 us)
     static __device__ __forceinline__ Raw load(const bf16raw* p, int k, int V) {
         if (p != nullptr && k + 8 <= V) return *(const u32x4h*)(p + k);
         unsigned t[8];

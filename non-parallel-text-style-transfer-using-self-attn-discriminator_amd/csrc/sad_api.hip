@@ -46,6 +46,7 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 std::atomic<int> g_no_persist{-1};                       // -1: not set -> SAD_NO_PERSIST of the environment, read once
 std::atomic<unsigned> g_spin_limit{LP_SPIN_LIMIT};       // bound of a hand-off wait inside the persistent recurrences
 std::atomic<int> g_withhold_fwd{-1}, g_withhold_bwd{-1}; // workgroup that exits at once (forces a hand-off timeout)
+std::atomic<int> g_wgrad_atomics{0};                     // 1: no slab for the gen-2 weight gradients (test hook)
 std::atomic<int> g_withhold_upper_only{0};               // 1: only in the launches of RNN layers above the first
 
 bool no_persist() {
@@ -1194,6 +1195,7 @@ int sad_debug_set(int32_t key, int64_t value) {
         case SAD_DBG_WITHHOLD_FWD: g_withhold_fwd.store((int)value); return 0;
         case SAD_DBG_WITHHOLD_BWD: g_withhold_bwd.store((int)value); return 0;
         case SAD_DBG_WITHHOLD_UPPER_ONLY: g_withhold_upper_only.store(value != 0 ? 1 : 0); return 0;
+        case SAD_DBG_WGRAD_ATOMICS: g_wgrad_atomics.store(value != 0 ? 1 : 0); return 0;
         default: return fail(-1, "unknown debug key %d", key);
     }
 }
@@ -1247,7 +1249,8 @@ int sad_param_grads_accumulate(const sad_dims* d, const sad_param_grads* g, cons
 
     // partial tiles go to the stream-K slab of K1 (idle here) and a second launch adds them up in fixed order; when a
     // launch's partial tiles do not fit the slab (very large M: many row splits) it falls back to fp32 atomics
-    float* slab_all = wl.bytes[SAD_WS_K1SLABS] != 0 ? at<float>(ws, wl.off[SAD_WS_K1SLABS]) : nullptr;
+    float* slab_all = wl.bytes[SAD_WS_K1SLABS] != 0 && !g_wgrad_atomics.load(std::memory_order_relaxed)
+                          ? at<float>(ws, wl.off[SAD_WS_K1SLABS]) : nullptr;
     auto slab_for = [&](long long tiles, int zs, long long tile_floats) {
         return (size_t)tiles * zs * tile_floats * 4 <= wl.bytes[SAD_WS_K1SLABS] ? slab_all : (float*)nullptr;
     };

@@ -24,7 +24,7 @@ EXPORTS = ("sad_version", "sad_last_error", "sad_padded_dims", "sad_packed_bytes
            "sad_inproj_fwd", "sad_inproj_bwd", "sad_lstm_fwd", "sad_lstm_bwd", "sad_attnpool_fwd", "sad_attnpool_bwd", "sad_debug_set", "sad_forward_noalloc",
            "sad_gumbel_st_step", "sad_gumbel_st_step_bwd", "sad_soft_finalize")
 
-DBG_NO_PERSIST, DBG_SPIN_LIMIT, DBG_WITHHOLD_FWD, DBG_WITHHOLD_BWD, DBG_WITHHOLD_UPPER_ONLY = 0, 1, 2, 3, 4
+DBG_NO_PERSIST, DBG_SPIN_LIMIT, DBG_WITHHOLD_FWD, DBG_WITHHOLD_BWD, DBG_WITHHOLD_UPPER_ONLY, DBG_WGRAD_ATOMICS = 0, 1, 2, 3, 4, 5
 
 
 class SadDims(ctypes.Structure):

@@ -228,3 +228,32 @@ def test_upper_layer_timeout_is_reported_and_next_forward_refuses():
     logits3, ws3 = run()                                            # reported once; this call runs
     ws3.check()
     assert torch.equal(logits3, logits0)
+
+
+@pytest.mark.parametrize("V", [9353, 9344, 300])
+def test_weight_gradients_atomic_fallback_matches_slab_path(V):
+    """Round 3's large weight-gradient kernels (wgrad2.hpp) normally store partial tiles to a slab that a second launch
+    reduces in fixed order; when a launch's partial tiles do not fit the slab they fall back to fp32 atomics
+    (SAD_DBG_WGRAD_ATOMICS forces that).  Both paths against the oracle, and against each other, at a ragged
+    vocabulary (last tile re-anchored at V - 128), a vocabulary that is a multiple of the tile, and a small one."""
+    from sad_amd import lib
+    B, T, E, H = 24, 9, 300, 512
+    lengths = synth.make_lengths(B, T, seed=V)
+    params = synth.make_params(V, E, H, seed=5)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=6, kind="dense", time_major=False)
+    mask = synth.transfer_mask(lengths, T)
+    labels = synth.make_labels(B, seed=V)
+    p = O.cast_params(params, np.float64)
+    f = O.forward(p, S.astype(np.float64), lengths, mask.copy(), True, labels=labels)
+    b = O.backward(p, f["cache"], O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B)), want_param_grads=True)
+    outs = []
+    try:
+        for atomics in (0, 1):
+            lib.debug_set(lib.DBG_WGRAD_ATOMICS, atomics)
+            outs.append(run_sad(params, S, lengths, mask, labels, s_dtype="bf16", param_grads=True)["grads"])
+    finally:
+        lib.debug_set(lib.DBG_WGRAD_ATOMICS, 0)
+    for k in ("embedding.weight", "rnn.weight_ih_l0", "rnn.weight_hh_l0_reverse", "linear_emb.weight", "rnn.bias_ih_l0"):
+        for g in outs:
+            assert relerr(g[k], b["grads"][k]) < 2e-2, k
+        assert relerr(outs[0][k], outs[1][k]) < 1e-5, k          # same products, different summation order only

@@ -41,6 +41,8 @@ def one():
     import bench
     dev = torch.device("cuda:0")
     w = dict(bench.WORKLOADS["cfg3"])
+    if os.environ.get("K1_V"):
+        w["V"] = int(os.environ["K1_V"])            # alignment probe: row pitch of S in bytes = 2 V
     params = synth.make_params(w["V"], w["E"], w["H"], w["L"], seed=21)
     pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})
     S, lengths, ln_dev, mask, labels = bench.make_inputs(w, 1234, dev)

@@ -1649,10 +1649,19 @@ __global__ __launch_bounds__(C::NT) void k_softemb_bwd(Shape s, const bf16raw* _
 //     also covers the stores of tile nt-1, which by then had a whole MFMA phase to drain.
 // PAIR: epi(tm, n, lo, hi) = columns [n, n+8) of this lane's row tm; else epi(tm, n, v) = [n, n+4).
 // ------------------------------------------------------------------------------------------------
-template <int KS, int PAIR, bool DB = false, class Epi = void>     // DB: two LDS tile buffers, one barrier per tile; PAIR: 0 = epi per accumulator tile, 1 = per pair of tiles, 2 = per 64-column tile (all of acc)
+// Timing-only ablations of the in-projection forward (tools/k1abl.py, -DSAD_IP_ABL=<bits>; results are garbage):
+// 1 no MFMA, 2 no LDS fragment reads and no MFMA, 4 no epilogue (no output stores), 8 no W tile loads, 16 no W tile LDS writes.
+#ifndef SAD_IP_ABL
+#define SAD_IP_ABL 0
+#endif
+template <int KS, int PAIR, bool DB = false, class Pre = void, class Epi = void>     // DB: two LDS tile buffers, one barrier per tile; PAIR: 0 = epi per accumulator tile, 1 = per pair of tiles, 2 = per 64-column tile (all of acc)
 __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, const int (&mrow)[2], bool wave_any,
                                         int block_any, const bf16raw* __restrict__ Bt, int nt0, int nt1,
-                                        unsigned char* Bs, Epi epi) {
+                                        unsigned char* Bs, Pre pre, Epi epi) {
+    // pre(nt): called in front of tile nt's MFMAs (DB form): global loads the epilogue needs (bias) go HERE.  vmcnt
+    // retires in order, so a load issued inside the epilogue is waited for behind the previous tile's output stores --
+    // every tile drained its predecessor's stores before it could store (and nothing overlapped: the ablations'
+    // phases added up).  Issued before the MFMAs, both have a whole MFMA phase to complete.
     constexpr int EP = KS * 32, BN = 64, NTH = 512;
     constexpr int ROWB = EP * 2;              // bytes per Bt row
     constexpr int CPR = EP / 8;               // 16-byte chunks per row
@@ -1689,7 +1698,9 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
         goff[i] = g * 8;                    // elements from the tile's first row (tile is contiguous)
     }
     u32x4 st[SCH];
+    if (DB && (SAD_IP_ABL & 8)) memset(st, 0, sizeof(st));
     auto load_tile = [&](int nt) {
+        if (DB && (SAD_IP_ABL & 8)) return;
         const bf16raw* base = Bt + (long long)nt * BN * EP;
 #pragma unroll
         for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
@@ -1713,6 +1724,10 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
             if (nt0 + 1 < nt1) load_tile(nt0 + 1);
             __syncthreads();
         }
+        // Role ablations (profiles/r03_inproj_fwd_ablation.txt): the phases of a tile add up -- staging 9 + fragment reads
+        // 8 + MFMA 15 + output stores 36 us of an 82 us launch (fixed part 14).  Tried and reverted: the epilogue of tile
+        // nt-1 issued beside the MFMAs of tile nt, waves 0-3 before and waves 4-7 (their SIMD mates) after their own
+        // MFMAs, accumulators double-buffered (256 VGPRs): 76 -> 81-82 us.
         for (int nt = nt0; nt < nt1; ++nt) {
             f32x4 acc[2][4];
 #pragma unroll
@@ -1723,17 +1738,25 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
                 const unsigned char* cur = Bs + ((nt - nt0) & 1) * TILEB;
                 if (nt + 1 < nt1) {
                     unsigned char* nxt = Bs + ((nt + 1 - nt0) & 1) * TILEB;
+                    if (!(SAD_IP_ABL & 16)) {
 #pragma unroll
-                    for (int i = 0; i < SCH; ++i) *(u32x4*)&nxt[soff[i]] = st[i];
+                        for (int i = 0; i < SCH; ++i) *(u32x4*)&nxt[soff[i]] = st[i];
+                    }
                     if (nt + 2 < nt1) load_tile(nt + 2);
                 }
-                if (wave_any) {
+                pre(nt);
+                if (wave_any && !(SAD_IP_ABL & 2)) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         bf16x8 bfr[4];
 #pragma unroll
                         for (int tn = 0; tn < 4; ++tn)
                             bfr[tn] = *(const bf16x8*)&cur[roff[tn] + (((ks * 4 + (lane >> 4)) ^ rsw[tn]) << 4)];
+                        if (SAD_IP_ABL & 1) {
+#pragma unroll
+                            for (int tn = 0; tn < 4; ++tn) asm volatile("" ::"v"(bfr[tn]));
+                            continue;
+                        }
 #pragma unroll
                         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1743,7 +1766,7 @@ __device__ __forceinline__ void rs_gemm(const bf16raw* __restrict__ A, int M, co
                 }
             }
             static_assert(!DB || PAIR == 2, "the double-buffered form is used with the per-tile epilogue");
-            epi(nt, acc);
+            if (!(SAD_IP_ABL & 4)) epi(nt, acc);
             if (block_any) __syncthreads();       // tile nt consumed by all, tile nt+1 written by all
         }
         return;
@@ -2318,6 +2341,7 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char* scr = ip_lds + 2 * 64 * KS * 64 + wave * 8192;        // [32 rows][64 cols] fp32, 256-byte rows
     const int M = s.M, G2 = 2 * s.Gp, ntn = s.Ncat / 64;
+    const long long gld = s.Gld, hp = s.Hp;
     const int n = nrows[0] < M ? nrows[0] : M;                           // list 0: rows with need != 0
     const long long U = (long long)((n + 255) / 256) * ntn;
     long long u = U * blockIdx.x / gridDim.x;
@@ -2352,13 +2376,25 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* 
             garow[tm] = ga_index(t, 0, b, 0, s.B, s.Hp);
         }
         const long long gadir = (long long)((s.B + 15) >> 4) * (s.Hp >> 2) * 256;     // ga_index(t, 1, ..) - ga_index(t, 0, ..)
-        rs_gemm<KS, 2, true>(X, M, mrow, wave_any, 1, wcat, nt0, nt1, Bs, [&](int nt, const f32x4 (&acc)[2][4]) {
+        f32x4 bias[4];                                                   // this tile's bias, loaded by pre()
+        rs_gemm<KS, 2, true>(X, M, mrow, wave_any, 1, wcat, nt0, nt1, Bs, [&](int nt) {
             if (!wave_any) return;
+            if (GA != nullptr && nt * 64 < G2) {                             // record layout: columns tn * 16 + 4 q ..
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) bias[tn] = *(const f32x4*)&bcat[nt * 64 + tn * 16 + 4 * (lane >> 4)];
+            } else {                                                         // row layout (after the LDS turn): columns 4 sc ..
+                bias[0] = *(const f32x4*)&bcat[nt * 64 + sc * 4];
+                bias[1] = bias[2] = bias[3] = bias[0];
+            }
+        }, [&](int nt, const f32x4 (&acc)[2][4]) {
+            if (!wave_any) return;
+            // retire the bias loads HERE, unconditionally: used first inside the row predicates below, they stay
+            // "pending" on the paths around them and hipcc puts s_waitcnt vmcnt(0) in front of EVERY store -- each
+            // store then waits for the one before it to complete
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) asm volatile("" : "+v"(bias[tn]));
             if (GA != nullptr && nt * 64 < G2) {
                 const int dir = nt * 64 >= s.Gp ? 1 : 0, ub = nt - dir * (s.Gp >> 6), q = lane >> 4;
-                f32x4 bias[4];
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) bias[tn] = *(const f32x4*)&bcat[nt * 64 + tn * 16 + 4 * q];
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)
                     if (mrow[tm] < M)
@@ -2376,15 +2412,15 @@ __global__ __launch_bounds__(512) void k_inproj_fwd_rs3(Shape s, const bf16raw* 
                 }
             }
             const int nn = nt * 64 + sc * 4;
-            const f32x4 bias = *(const f32x4*)&bcat[nn];
             float* base = nn < G2 ? G + nn : Kk + (nn - G2);
-            const long long ld = nn < G2 ? s.Gld : s.Hp;
+            const long long ld = nn < G2 ? gld : hp;       // (selected between the Shape fields themselves, hipcc fetched
+                                                           // the kernel argument with a per-lane global load: vmcnt(0) here)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int r = (lane >> 4) + 4 * i;
                 const f32x4 v = *(const f32x4*)&scr[r * 256 + ((sc ^ (r & 15)) << 4)];
                 // written once, read once by the recurrence much later: keep it out of the L2's way
-                if (srow[i] >= 0) __builtin_nontemporal_store(v + bias, (f32x4*)(base + (long long)srow[i] * ld));
+                if (srow[i] >= 0) __builtin_nontemporal_store(v + bias[0], (f32x4*)(base + (long long)srow[i] * ld));
             }
         });
     }

@@ -11,10 +11,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.path.join(ROOT, "tools", "abl")
-VARIANTS = [0, 1, 3, 4, 12, 16, 28, 19, 7, 15, 31]
+KERNEL = os.environ.get("ABL_KERNEL", "k1")          # k1: -DSAD_K1_ABL, sad_softemb_fwd;  ip: -DSAD_IP_ABL, sad_inproj_fwd
+VARIANTS = [0, 1, 3, 4, 12, 16, 28, 19, 7, 15, 31] if KERNEL == "k1" else [0, 1, 3, 4, 8, 24, 7, 27, 31]
 NAMES = {0: "full kernel", 1: "no MFMA", 3: "no fragment reads, no MFMA", 4: "no S loads", 12: "no S loads, no S LDS writes",
          16: "no W loads", 28: "no loads at all (S, W), no S LDS writes", 19: "W stream only feeds nobody: no W loads, no compute",
          7: "S LDS writes + W loads only (no S loads, no compute)", 15: "W loads only", 31: "barriers only"}
+if KERNEL == "ip":     # bits: 1 no MFMA, 2 no fragment reads + no MFMA, 4 no epilogue, 8 no W loads, 16 no W LDS writes
+    NAMES = {0: "full kernel", 1: "no MFMA", 3: "no fragment reads, no MFMA", 4: "no epilogue (no output stores)", 8: "no W loads",
+             24: "no W loads, no W LDS writes", 7: "W staging only (no compute, no epilogue)", 27: "epilogue only", 31: "barriers only"}
 
 
 def build():
@@ -22,9 +26,9 @@ def build():
     src = os.path.join(ROOT, "non-parallel-text-style-transfer-using-self-attn-discriminator_amd", "csrc", "sad_api.hip")
     procs = []
     for v in VARIANTS:
-        out = os.path.join(ABL, "libsad_abl%d.so" % v)
+        out = os.path.join(ABL, "libsad_%s_abl%d.so" % (KERNEL, v))
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                                       "-Wno-unused-function", "-DSAD_K1_ABL=%d" % v, "-o", out, src]))
+                                       "-Wno-unused-function", "-DSAD_%s_ABL=%d" % ("K1" if KERNEL == "k1" else "IP", v), "-o", out, src]))
         if len(procs) == 4:
             for p in procs:
                 assert p.wait() == 0
@@ -54,7 +58,10 @@ def one():
     d = lib.dims(w["B"], w["T"], w["V"], w["E"], w["H"], w["L"])
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    fn = lambda: L.sad_softemb_fwd(ctypes.byref(d), p(pw.buf), p(S), lib.SRC_BF16, w["V"], w["B"] * w["V"], p(ws.buf), st)
+    if KERNEL == "k1":
+        fn = lambda: L.sad_softemb_fwd(ctypes.byref(d), p(pw.buf), p(S), lib.SRC_BF16, w["V"], w["B"] * w["V"], p(ws.buf), st)
+    else:
+        fn = lambda: L.sad_inproj_fwd(ctypes.byref(d), p(pw.buf), p(ws.buf), st)
     sec = bench.time_launches(fn, iters=20, warm=3)
     print("%8.1f us" % (sec * 1e6), flush=True)
 
@@ -66,6 +73,6 @@ if __name__ == "__main__":
         one()
     else:
         for v in VARIANTS:
-            env = dict(os.environ, SAD_LIB=os.path.join(ABL, "libsad_abl%d.so" % v))
+            env = dict(os.environ, SAD_LIB=os.path.join(ABL, "libsad_%s_abl%d.so" % (KERNEL, v)))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True, timeout=300)
             print("ABL=%2d %-58s %s" % (v, NAMES[v], r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else "FAILED " + r.stderr[-300:]), flush=True)

@@ -61,6 +61,12 @@ __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigne
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
 }
 
+// 1: poll the group counter with a scalar load (see lp_counter).  Measured (round 3): correct, and no faster -- forward
+// 231 us either way, BPTT 330 -> 338 us, B = 64 0.342 -> 0.356 ms: the waves' first fragment wait stands behind the same
+// older operations the vector poll stood behind.  Kept as a build switch.
+#ifndef SAD_SCALAR_POLL
+#define SAD_SCALAR_POLL 0
+#endif
 constexpr int LP_BM = 128;                                   // sentences per tile (= LF_BM = LB_BM)
 constexpr int LP_SYNC_PITCH = 32;                            // counter pitch in 4-byte words (128-B lines)
 constexpr int LP_BM_MIN = 32;                                // smallest sentence tile (BPTT at small batches)
@@ -79,11 +85,23 @@ __device__ __forceinline__ int lp_wswz(int col, int chunk, int cmask) { return c
 // (a NaN h or dZ propagates through every later product) instead of passing silently.
 // `hostflag` (or NULL): a word of host-mapped memory the library owns per device; raised too, so that the NEXT
 // sad_forward on the device can refuse with the reason without anybody synchronising (sad_api.hip).
+// `scalar` (the group sits on one XCD: its counter lives in that XCD's L2): the counter is read with a SCALAR load
+// (glc: past the scalar cache).  A vector load's result is waited for with vmcnt, which retires in order: the poll
+// of a step stood behind the polling wave's own plain stores of the step before and behind the private operand
+// loads issued in front of it, whatever the counter said.
+__device__ __forceinline__ unsigned lp_counter(gu32* counter, bool scalar) {
+    if (scalar) {
+        unsigned v;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(counter) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(counter, SAD_RLX_AGENT);
+}
 __device__ __forceinline__ void lp_wait(gu32* counter, unsigned target, unsigned spin_limit, gu32* errword,
-                                        volatile unsigned* dead, unsigned* hostflag, unsigned code) {
+                                        volatile unsigned* dead, unsigned* hostflag, unsigned code, bool scalar = false) {
     if (*dead) return;
     unsigned spins = 0;
-    while (__hip_atomic_load(counter, SAD_RLX_AGENT) < target) {
+    while (lp_counter(counter, scalar) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > spin_limit) {
             __hip_atomic_store(errword, 1u, SAD_RLX_AGENT);
@@ -161,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     // bm: sentences per tile (LF_BM, or 64 / 32 at small batches: waves 32 w >= bm idle -- see lstm_fwd_tile)
     const int ctiles = Gp / LF_BN, rtiles = (B + bm - 1) / bm, groups = rtiles * 2;
     int group, ct;
-    if ((gridDim.x / ctiles) % 8 == 0) {
+    const bool xcd_local = (gridDim.x / ctiles) % 8 == 0;
+    if (xcd_local) {
         // blocks b, b+8, ... share an XCD (speed only): keep a group on one XCD, so that its hand-offs are served
         // by that XCD's L2.  The host pads the grid to a multiple of 8 groups when that still fits the device;
         // the workgroups of the padding leave at once.
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
         LF_PROF_T(0)
         if (done > 0) {
-            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 1u);
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 1u, xcd_local && SAD_SCALAR_POLL);
             LF_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
             __syncthreads();
@@ -463,7 +482,8 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     // bm: sentences per tile (LB_BM, or 64 / 32 at small batches: waves 16 w >= bm idle -- see lstm_bwd_tile)
     const int ctiles = Hp / LB_BN, rtiles = (B + bm - 1) / bm, groups = rtiles * 2;
     int group, ct;
-    if ((gridDim.x / ctiles) % 8 == 0) {        // blocks b, b+8, ... share an XCD (speed only; see the forward kernel)
+    const bool xcd_local = (gridDim.x / ctiles) % 8 == 0;
+    if (xcd_local) {                            // blocks b, b+8, ... share an XCD (speed only; see the forward kernel)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         group = xcd + 8 * (slot / ctiles);
         ct = slot % ctiles;
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         LB_PROF_T(0)
         if (done > 0) {
-            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 2u);
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 2u, xcd_local && SAD_SCALAR_POLL);
             LB_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();

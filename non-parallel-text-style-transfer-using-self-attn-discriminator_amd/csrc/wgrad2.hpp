@@ -7,21 +7,21 @@
 // 0.8 us per stage against 0.27 us of MFMA), staged every tile through two register slots (228 VGPRs for 40
 // accumulators; 128-column tiles spilled) and took 354 / 197 / 191 us (0.11-0.15 of the MFMA peak).  Here
 //   * tiles are 128 x 320 (x 256 for W_hh): 56 KB per stage for 5.2 MFLOP;
-//   * the short operand (X, dX, Hs: L2-resident, re-read by every column tile) goes global -> LDS by LDS-direct
-//     loads (global_load_lds_dwordx4: no registers, no ds_write); the long operand (DZ, S: streamed from HBM once)
-//     passes through three register sets (tiles k+2, k+3 in flight: HBM latency, not bandwidth, is what a single
-//     tile in flight ran at);
+//   * three wave roles in a 1024-thread workgroup (wgrad2_core below): the short operand (X, dX, Hs: L2-resident,
+//     re-read by every column tile) goes global -> LDS by LDS-direct loads (global_load_lds_dwordx4: no registers, no
+//     ds_write) issued by 4 loader waves, three LDS stages; the long operand (DZ, S: streamed from HBM once) passes
+//     through FOUR static register sets of 4 other loader waves (a wave that also holds the 80 accumulators of its
+//     share of the tile has room for one set only, and one tile in flight ran at HBM latency: 2-3 us per stage);
+//     8 compute waves multiply;
 //   * the LDS tiles are UNPADDED row-major images (an LDS-direct instruction writes 64 consecutive 16-byte chunks)
 //     with the 32-byte column pairs XOR-swizzled per row, so that the transposing fragment reads
 //     (ds_read_b64_tr_b16, see wgrad.hpp) stay conflict-free: a half wave reads 8 rows x 32 bytes, which must fall
 //     into 8 different 8-bank groups; with pitch P the row term is (P/32 * r) mod 8 -- 0 for P = 256 / 512,
 //     4r mod 8 for P = 640 -- and the swizzle supplies the missing bits (r & 7, resp. (r >> 1) & 3);
-//   * two LDS stages, loads of tile k+2 issued right after tile k is consumed, counted vmcnt waits (only the oldest
-//     tile is waited for).  The workgroup's slice of the compacted row list is copied into LDS once: fetched per
-//     tile by vector loads, the pending index register crossed the loop's back edge and hipcc put s_waitcnt
-//     vmcnt(0) in front of the copy that carries it over -- behind the LDS-direct loads issued a moment before,
-//     i.e. no load was ever in flight during the MFMAs.
-// Results are accumulated with fp32 atomics into the caller's state_dict-layout tensors exactly like wgrad.hpp does.
+//   * every workgroup stores its partial tile to a slab and a second launch reduces the row splits of a tile in fixed
+//     order (no fp32 atomics: 8-10 M atomic adds per launch took ~150 us whatever stood in front of them); atomics
+//     remain the fallback when the partial tiles of a launch do not fit the slab (SAD_DBG_WGRAD_ATOMICS tests it).
+// What hipcc's waitcnt pass does to such loops, and how each case is avoided here: DESIGN.md, "Parameter gradients".
 #pragma once
 #include "wgrad.hpp"
 
@@ -31,35 +31,13 @@ namespace sad {
 template <int BN> struct W2Swz { static constexpr int kind = ((BN * 2 / 32) % 8 == 0) ? 0 : 1; };
 template <int KIND> __device__ __forceinline__ int w2_swz(int r) { return KIND == 0 ? (r & 7) : ((r >> 1) & 3); }
 
-// Row indices come out of LDS through inline asm: an ordinary LDS load while LDS-direct loads are pending makes
-// hipcc's waitcnt pass (which cannot tell the two LDS regions apart) wait for ALL of them -- s_waitcnt vmcnt(0) in
-// front of every tile's MFMAs.  Inline asm is invisible to that pass; the lgkmcnt wait is ours.
+// LDS writes of a wave that has LDS-direct loads in flight go through inline asm: an ordinary LDS access while
+// LDS-direct loads are pending makes hipcc's waitcnt pass (which cannot tell the LDS regions apart) wait for ALL of
+// them -- s_waitcnt vmcnt(0).  Inline asm is invisible to that pass; the lgkmcnt wait is the caller's.
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_u8*)p; }
-__device__ __forceinline__ void lds_zero16(void* p) {
-    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-    asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(p)), "v"(z) : "memory");
-}
 __device__ __forceinline__ void lds_store16b(void* p, unsigned v) {
     asm volatile("ds_write_b16 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_read_ints(int (&v)[N], const unsigned (&addr)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(v[i]) : "v"(addr[i]));
-    static_assert(N >= 1 && N <= 8, "1..8 values");
-    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
-    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
-    if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
-    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-    if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
-    if constexpr (N == 6)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
-    if constexpr (N == 7)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
-    if constexpr (N == 8)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
 
 template <int BN1_, int BN2_, int W1_, int W2_>

@@ -2019,6 +2019,11 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws(Shape s, const bf16raw* 
 // 342 us), element-wise shifted LDS writes from the compute waves (48 ds_write_b16 per lane: 302 us in the step),
 // every wave storing a share of the tile (321 us), four compute waves of 64 rows (no change).
 // ------------------------------------------------------------------------------------------------
+// Timing-only ablations (tools/k1abl.py ABL_KERNEL=k1b, -DSAD_K1B_ABL=<bits>; results are garbage):
+// 1 store waves skip the global stores, 2 compute waves skip the MFMAs, 4 loader waves skip the W_emb loads.
+#ifndef SAD_K1B_ABL
+#define SAD_K1B_ABL 0
+#endif
 template <int KS>
 __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw* __restrict__ DX,
                                                         const unsigned char* __restrict__ need,
@@ -2077,7 +2082,10 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
                     vv[i] = *(const u32x4*)&buf[r * 128 + ((c ^ (r & 7)) << 4)];
                 }
                 const int seg = (nt0 + it - 1) * BN;             // first stream position of this tile
-                if (seg - 31 >= col_lo && seg + BN <= col_hi) {
+                if (SAD_K1B_ABL & 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(vv[i]));
+                } else if (seg - 31 >= col_lo && seg + BN <= col_hi) {
                     // interior tile (workgroup-uniform): every chunk lies inside the column range
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
@@ -2123,7 +2131,9 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
             goff[i] = g * 8;
         }
         u32x4 st[SCH];
+        if (SAD_K1B_ABL & 4) memset(st, 0, sizeof(st));
         auto load_tile = [&](int k) {                          // clamped, never skipped
+            if (SAD_K1B_ABL & 4) return;
             const bf16raw* base = wemb + (long long)(nt0 + (k < ntl ? k : ntl - 1)) * BN * EP;
 #pragma unroll
             for (int i = 0; i < SCH; ++i) st[i] = *(const u32x4*)(base + goff[i]);
@@ -2259,6 +2269,10 @@ __global__ __launch_bounds__(768) void k_softemb_bwd_ws2(Shape s, const bf16raw*
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
                         bfr[h] = *(const bf16x8*)&buf[((ks & 1) ? b_odd + 64 * (ks - 1) : b_even + 64 * ks) + (2 * pr + h) * 16 * ROWB];
+                    if (SAD_K1B_ABL & 2) {
+                        asm volatile("" ::"v"(bfr[0]), "v"(bfr[1]));
+                        continue;
+                    }
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll

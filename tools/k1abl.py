@@ -12,10 +12,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.path.join(ROOT, "tools", "abl")
 KERNEL = os.environ.get("ABL_KERNEL", "k1")          # k1: -DSAD_K1_ABL, sad_softemb_fwd;  ip: -DSAD_IP_ABL, sad_inproj_fwd
-VARIANTS = [0, 1, 3, 4, 12, 16, 28, 19, 7, 15, 31] if KERNEL == "k1" else [0, 1, 3, 4, 8, 24, 7, 27, 31]
+VARIANTS = {"k1": [0, 1, 3, 4, 12, 16, 28, 19, 7, 15, 31], "ip": [0, 1, 3, 4, 8, 24, 7, 27, 31], "k1b": [0, 1, 2, 4, 3, 6, 7]}[KERNEL]
 NAMES = {0: "full kernel", 1: "no MFMA", 3: "no fragment reads, no MFMA", 4: "no S loads", 12: "no S loads, no S LDS writes",
          16: "no W loads", 28: "no loads at all (S, W), no S LDS writes", 19: "W stream only feeds nobody: no W loads, no compute",
          7: "S LDS writes + W loads only (no S loads, no compute)", 15: "W loads only", 31: "barriers only"}
+if KERNEL == "k1b":    # bits: 1 no global stores, 2 no MFMA, 4 no W loads
+    NAMES = {0: "full kernel", 1: "no global stores", 2: "no MFMA", 4: "no W loads", 3: "no stores, no MFMA", 6: "stores only (no MFMA, no W loads)",
+             7: "barriers + LDS traffic only"}
 if KERNEL == "ip":     # bits: 1 no MFMA, 2 no fragment reads + no MFMA, 4 no epilogue, 8 no W loads, 16 no W LDS writes
     NAMES = {0: "full kernel", 1: "no MFMA", 3: "no fragment reads, no MFMA", 4: "no epilogue (no output stores)", 8: "no W loads",
              24: "no W loads, no W LDS writes", 7: "W staging only (no compute, no epilogue)", 27: "epilogue only", 31: "barriers only"}
@@ -28,7 +31,7 @@ def build():
     for v in VARIANTS:
         out = os.path.join(ABL, "libsad_%s_abl%d.so" % (KERNEL, v))
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                                       "-Wno-unused-function", "-DSAD_%s_ABL=%d" % ("K1" if KERNEL == "k1" else "IP", v), "-o", out, src]))
+                                       "-Wno-unused-function", "-DSAD_%s_ABL=%d" % ({"k1": "K1", "ip": "IP", "k1b": "K1B"}[KERNEL], v), "-o", out, src]))
         if len(procs) == 4:
             for p in procs:
                 assert p.wait() == 0
@@ -58,7 +61,13 @@ def one():
     d = lib.dims(w["B"], w["T"], w["V"], w["E"], w["H"], w["L"])
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    if KERNEL == "k1":
+    if KERNEL == "k1b":
+        full = os.environ.get("K1B_FULL")           # every row needed (lengths = T)
+        dS = torch.empty_like(S)
+        if full:
+            ws.view("NEED", torch.uint8).fill_(1)
+        fn = lambda: L.sad_softemb_bwd(ctypes.byref(d), p(pw.buf), p(dS), lib.SRC_BF16, w["V"], w["B"] * w["V"], p(ws.buf), st)
+    elif KERNEL == "k1":
         fn = lambda: L.sad_softemb_fwd(ctypes.byref(d), p(pw.buf), p(S), lib.SRC_BF16, w["V"], w["B"] * w["V"], p(ws.buf), st)
     else:
         fn = lambda: L.sad_inproj_fwd(ctypes.byref(d), p(pw.buf), p(ws.buf), st)

@@ -1,10 +1,18 @@
-"""Role ablations of K1 (k_softemb_fwd_sk) at cfg3: which role sets the pace of a k-tile?
+"""Role ablations of the three wave-specialised GEMM kernels at cfg3: which role sets the pace of a tile?
 
-    python tools/k1abl.py build          # here: variant libraries tools/abl/libsad_abl<bits>.so (-DSAD_K1_ABL=<bits>)
-    python tools/k1abl.py                # on the GPU box: times sad_softemb_fwd with every variant (one process each)
+    ABL_KERNEL=k1|ip|k1b python tools/k1abl.py build   # here: variant libraries tools/abl/libsad_<kernel>_abl<bits>.so
+    ABL_KERNEL=k1|ip|k1b python tools/k1abl.py         # on the GPU box: times the stage entry point with every variant
 
-bits: 1 no MFMA, 2 no LDS fragment reads + no MFMA, 4 no S global loads, 8 no S LDS writes, 16 no W LDS-direct loads.
-Variant results are garbage by construction; only the launch time is read."""
+    k1  (default)  K1  k_softemb_fwd_sk, -DSAD_K1_ABL:  1 no MFMA, 2 no LDS fragment reads + no MFMA, 4 no S global loads,
+                   8 no S LDS writes, 16 no W LDS-direct loads                     -> profiles/r03_k1_role_ablation.txt
+    ip             in-projection forward k_inproj_fwd_rs3, -DSAD_IP_ABL: 1 no MFMA, 2 no fragment reads + no MFMA,
+                   4 no epilogue, 8 no W loads, 16 no W LDS writes                 -> profiles/r03_inproj_fwd_ablation.txt
+    k1b            K1' k_softemb_bwd_ws2, -DSAD_K1B_ABL: 1 no global stores, 2 no MFMA, 4 no W_emb loads
+                   (K1B_FULL=1: every row needed)                                  -> profiles/r03_k1b_role_ablation.txt
+    K1_V=<V>       vocabulary size of the probe (row alignment of S)
+
+Variant results are garbage by construction; only the launch time is read.  The variant libraries are selected through
+SAD_LIB, one process per variant."""
 import os
 import subprocess
 import sys

@@ -155,7 +155,7 @@ __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
 // debug build only: phase timers (100 MHz wall clock) of one workgroup -> the free words after the timeout words
 #define LF_PROF_DECL unsigned long long pt[7] = {0,0,0,0,0,0,0}, pa[7] = {0,0,0,0,0,0,0}; unsigned psteps = 0;
 #define LF_PROF_T(i) pt[i] = wall_clock64();
-#define LF_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0][0]), "v"(acc[1][3][0])); }
+#define LF_PROF_ACC { float tmp_; asm volatile("v_add_f32 %0, %1, %2" : "=v"(tmp_) : "v"(acc[0][0][0]), "v"(acc[TM - 1][3][0])); }
 #define LF_PROF_END if (done > 1) { for (int i = 1; i < 7; ++i) pa[i] += pt[i] - pt[i - 1]; ++psteps; }
 #define LF_PROF_OUT if (tid == 0 && group == SAD_LF_PROF && ct == 3) { unsigned long long* o = (unsigned long long*)(sync + (size_t)lp_err_line(s.B) * LP_SYNC_PITCH + 8); for (int i = 1; i < 7; ++i) o[i - 1] = pa[i]; o[6] = psteps; }
 #else
@@ -165,6 +165,11 @@ __host__ __device__ inline size_t lstm_fwd_xchg_bytes(int B, int Hp) {
 #define LF_PROF_END
 #define LF_PROF_OUT
 #endif
+// MS (tiles of 32 / 64 sentences, small batches): a wave takes ONE 16-sentence block instead of two, so a tile of 64
+// keeps all four waves busy and a tile of 32 two of them (it ran on one: 128 MFMAs and two round trips of loads per step
+// on one SIMD), and all of a block's h (16 KB at H = 512) is requested at once.  The sum over K keeps its order: the
+// results are bit-identical to the full-tile form's.
+template <bool MS>
 __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int* __restrict__ lens,
                                                           const bf16raw* __restrict__ whh, float* __restrict__ G,
                                                           float* __restrict__ Cs, bf16raw* __restrict__ Hs, bf16raw* HX,
@@ -231,17 +236,21 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     const int j = ct * 16 + u4;                              // first of this lane's 4 hidden units
     const int sblocks = rtiles * (bm / 16);
     const size_t xpar = (size_t)2 * sblocks * Hp * 16;       // elements of one parity of the image
-    int brow[2], blen[2];
-    unsigned xrow[2];                                        // image offset (elements) of this lane's sentence, chunk 0
-    f32x4 creg[2];
+    constexpr int TM = MS ? 1 : 2;                           // 16-sentence blocks (MFMA row fragments) of a wave
+    constexpr int NS = MS ? 2 * LF_NS : LF_NS;               // fragment sets in flight (a set: 4 k-steps of TM blocks)
+    const int sblk = MS ? wave : wave * 2;                   // first block of this wave
+    int brow[TM], blen[TM];
+    unsigned xrow[TM];                                       // image offset (elements) of this lane's sentence, chunk 0
+    f32x4 creg[TM];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        brow[tm] = b0 + wave * 32 + tm * 16 + (lane & 15);
-        blen[tm] = (wave * 32 + tm * 16 < bm && brow[tm] < B) ? lens[brow[tm]] : 0;
+    for (int tm = 0; tm < TM; ++tm) {
+        brow[tm] = b0 + (sblk + tm) * 16 + (lane & 15);
+        blen[tm] = ((sblk + tm) * 16 < bm && brow[tm] < B) ? lens[brow[tm]] : 0;
         creg[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-        xrow[tm] = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave * 2 + tm) * cpr * 128 + (lane & 15) * 8);
+        xrow[tm] = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + sblk + tm) * cpr * 128 + (lane & 15) * 8);
     }
     const int nks = Hp / 32;
+    const int nsets = (nks + 3) / 4;
     unsigned done = 0;
     LF_PROF_DECL
 
@@ -251,10 +260,10 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         const int tp = dir ? t + 1 : t - 1;
         // accumulators start from the gate pre-activations of this step (private to the workgroup,
         // independent of h: issued before the wait)
-        f32x4 acc[2][4];
-        bool act[2];
+        f32x4 acc[TM][4];
+        bool act[TM];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
             act[tm] = blen[tm] > t;
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -281,16 +290,16 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
             // ---- h_{tp} of this wave's 32 sentences: LF_NS sets of 4 k-steps (4 KB per wave each) in flight,
             //      16-byte sc1 loads straight into MFMA fragment registers; gates += h_{tp} . W_hh^T
             //      (a wave without sentences skips it)
-            if (wave * 32 < bm && b0 + wave * 32 < B) {
+            if (sblk * 16 < bm && b0 + sblk * 16 < B) {
             const __amdgpu_buffer_rsrc_t rs = lp_rsrc(HX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
-            unsigned voff[2];
+            unsigned voff[TM];
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) voff[tm] = blen[tm] > tp ? (xrow[tm] + (unsigned)q * 128u) * 2u : LP_OOB;
-            u32x4 a[LF_NS][2][4];
+            for (int tm = 0; tm < TM; ++tm) voff[tm] = (blen[tm] > tp && act[tm]) ? (xrow[tm] + (unsigned)q * 128u) * 2u : LP_OOB;
+            u32x4 a[NS][TM][4];
             auto load_set = [&](auto slot, int sg) {
                 constexpr int S = decltype(slot)::value;
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
                         a[S][tm][kk] = lp_load16_sc1(rs, sg * 4 + kk < nks ? voff[tm] + (unsigned)(sg * 4 + kk) * 1024u : LP_OOB);
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                             bfr[tn] = *(const bf16x8*)(Wl + (long long)col * Hp + lp_wswz(col, ch, cmask) * 8);
                         }
 #pragma unroll
-                        for (int tm = 0; tm < 2; ++tm) {
+                        for (int tm = 0; tm < TM; ++tm) {
                             const bf16x8 af = __builtin_bit_cast(bf16x8, a[S][tm][kk]);
 #pragma unroll
                             for (int tn = 0; tn < 4; ++tn)
@@ -319,15 +328,14 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
             };
             // a real loop (not unrolled): straight-line code lets the scheduler hoist every LDS fragment
             // read to the top and spill
-            const int nsets = (nks + 3) / 4;
 #pragma unroll
-            for (int i = 0; i < LF_NS; ++i) static_for<LF_NS>([&](auto sl) { if (decltype(sl)::value == i) load_set(sl, i); });
+            for (int i = 0; i < NS; ++i) static_for<NS>([&](auto sl) { if (decltype(sl)::value == i) load_set(sl, i); });
 #pragma nounroll
-            for (int sg = 0; sg < nsets; sg += LF_NS) {
-                static_for<LF_NS>([&](auto sl) {
+            for (int sg = 0; sg < nsets; sg += NS) {
+                static_for<NS>([&](auto sl) {
                     constexpr int I = decltype(sl)::value;
                     mma_set(sl, sg + I);
-                    load_set(sl, sg + LF_NS + I);
+                    load_set(sl, sg + NS + I);
                 });
             }
             }
@@ -335,10 +343,11 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         LF_PROF_ACC
         LF_PROF_T(3)
         // ---- cell update; publish h_t first, the private stores (Hs, gates, c) after the signal -------
-        f32x4 gi[2], gf[2], gg[2], go[2];
+        f32x4 gi[TM], gf[TM], gg[TM], go[TM];
         u32x2 hp[2];
+        hp[1] = u32x2{0u, 0u};
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
             hp[tm] = u32x2{0u, 0u};
             if (!act[tm]) continue;
             const f32x4 pi = acc[tm][0], pf = acc[tm][1], pg = acc[tm][2], po = acc[tm][3];
@@ -374,10 +383,10 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         // quad-row holds 8 consecutive units of row fragment 0, an odd one of row fragment 1
         u32x4 hv = lp_pair16(hp[0], hp[1]);
         if (*dead) hv = u32x4{LP_NAN2, LP_NAN2, LP_NAN2, LP_NAN2};   // timed out: never publish results of stale h
-        const int tmq = q & 1;
-        const bool actq = tmq ? act[1] : act[0];
+        const int tmq = q & 1;                               // MS: odd quad-rows hold the (absent) second block
+        const bool actq = tmq ? (TM == 2 && act[TM - 1]) : act[0];
         lp_store16_sc1(lp_rsrc(HX + (done & 1) * xpar, (unsigned)(xpar * 2)),
-                       actq ? ((tmq ? xrow[1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u) * 2u : LP_OOB, hv);
+                       actq ? ((tmq ? xrow[TM - 1] : xrow[0]) + (unsigned)(ct * 2 + (q >> 1)) * 128u) * 2u : LP_OOB, hv);
         LF_PROF_T(4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains its sc1 stores
         LF_PROF_T(5)
@@ -385,11 +394,11 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
         ++done;
         if (actq) {
-            const long long row = ((long long)t * B + (tmq ? brow[1] : brow[0])) * 2 + dir;
+            const long long row = ((long long)t * B + (tmq ? brow[TM - 1] : brow[0])) * 2 + dir;
             *(u32x4*)&Hs[row * Hp + ct * 16 + (q >> 1) * 8] = hv;
         }
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
             if (!act[tm]) continue;
             if (GA != nullptr) {
                 ga_store(GA + ga_index(t, dir, brow[tm], j, B, Hp), gi[tm], gf[tm], gg[tm], go[tm]);
@@ -443,6 +452,8 @@ __host__ __device__ inline int lstm_bwd_tile(int B, int Hp, int cus) {
     return LB_BM;
 }
 __host__ __device__ inline size_t lstm_bwd_persist_lds_bytes(int Gp) { return (size_t)LB_BN * Gp * 2 + 16; }
+// K-split form (tiles of 32 / 64 sentences): partial dh of up to 6 helper waves, 2 x f32x4 per lane
+constexpr size_t LB_RED_BYTES = 6 * 2 * 64 * 16;
 // Hand-off image of dZ between the workgroups of a group, two step parities: laid out so that the 16
 // lanes of a quarter wave (16 sentences, one 8-column chunk = one MFMA fragment piece each) touch 256
 // contiguous bytes -- fragments loaded straight from the row-major DZ touched 16 cache lines per
@@ -467,6 +478,16 @@ __host__ __device__ inline size_t lstm_bwd_xchg_bytes(int B, int Gp) {
 #define LB_PROF_END
 #define LB_PROF_OUT
 #endif
+// KS (tiles of 32 / 64 sentences, small batches): the tile has only sb = bm / 16 sentence blocks for the 8 waves, and one
+// wave keeps just 8 KB of hand-off loads in flight -- a lone wave per block read its 64 KB per step as a chain of eight
+// round trips.  Wave w takes block w % sb and part w / sb of ks = 8 / sb parts of the K range; the waves of part 0 own the
+// block (operands, gate derivatives, stores), the others leave their partial dh in LDS, and the owner adds them in a fixed
+// order (results stay reproducible bit for bit).  One more workgroup barrier per step.
+// Canonical order of the sum over the gate columns, the same in every form of the kernel (so that a batch gives the same
+// bits whatever tile its size selects): four parts with boundaries at whole rounds of LB_NS fragment sets, each summed
+// front to back into its own accumulator, then (p0 + p1) + (p2 + p3).
+__device__ __forceinline__ int lb_part(int p, int nsg) { return LB_NS * (p * ((nsg + LB_NS - 1) / LB_NS) / 4); }
+template <bool KS>
 __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __restrict__ lens,
                                                          const bf16raw* __restrict__ whhT, const float* __restrict__ G,
                                                          const float* __restrict__ Cs, const float* __restrict__ DHFIN,
@@ -527,10 +548,13 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         __syncthreads();
         maxlen = *red_max;
     }
-    // this lane: sentence b0 + 16*wave + (lane & 15); unit quads j0 + 16*tn + 4*(lane >> 4), tn = 0, 1
-    const int b = b0 + wave * 16 + (lane & 15);
-    const bool mine = wave * 16 < bm && b < B;
-    const int len = mine ? lens[b] : 0;
+    // this lane: sentence b0 + 16*sblk + (lane & 15); unit quads j0 + 16*tn + 4*(lane >> 4), tn = 0, 1
+    const int sb = KS ? bm / 16 : 8, ks = 8 / sb;
+    const int sblk = KS ? wave % sb : wave, kq = KS ? wave / sb : 0;
+    const int b = b0 + sblk * 16 + (lane & 15);
+    const int rlen = (sblk * 16 < bm && b < B) ? lens[b] : 0;   // K loop: every wave of the block
+    const bool mine = kq == 0 && sblk * 16 < bm && b < B;        // owner of the sentence: operands, derivatives, stores
+    const int len = mine ? rlen : 0;
     int ju[2], pcu[2];
     f32x4 dcreg[2];
 #pragma unroll
@@ -543,7 +567,9 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     // hand-off image of dZ (see lstm_bwd_xchg_bytes): [parity][dir][16-sentence block][8-column chunk][16][8]
     const int sblocks = rtiles * (bm / 16);
     const size_t xpar = (size_t)2 * sblocks * Gp * 16;       // elements of one parity
-    const unsigned xrow = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + wave) * (Gp / 8) * 128 + (lane & 15) * 8);
+    const unsigned xrow = (unsigned)(((size_t)dir * sblocks + (b0 >> 4) + sblk) * (Gp / 8) * 128 + (lane & 15) * 8);
+    // this wave's share of the K range (all of it unless KS): 4 / ks of the four parts
+    const int sg0 = lb_part(kq * (4 / ks), nsg), sg1r = lb_part((kq + 1) * (4 / ks), nsg), sg1 = min(sg1r, nsg);
     unsigned done = 0;
     int t_carry = -1;                                        // step whose c is held in eccarry (per lane)
     f32x4 eccarry[2];
@@ -604,41 +630,81 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
             __syncthreads();
             LB_PROF_T(2)
             // ---- dh = dZ_{tn} . W_hh for this wave's 16 sentences (a wave without sentences skips it) --
-            if (wave * 16 < bm && b0 + wave * 16 < B) {
-            const bool rowok = len > tn_ && act;
+            if (sblk * 16 < bm && b0 + sblk * 16 < B) {
+            const bool rowok = rlen > tn_ && rlen > t;
             const __amdgpu_buffer_rsrc_t rs = lp_rsrc(DZX + ((done - 1) & 1) * xpar, (unsigned)(xpar * 2));
             const unsigned voff = rowok ? (xrow + (unsigned)(lane >> 4) * 128u) * 2u : LP_OOB;
             auto load_set = [&](int sg, u32x4 (&f)[4]) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f[q] = lp_load16_sc1(rs, sg < nsg ? voff + (unsigned)(sg * 16 + q * 4) * 256u : LP_OOB);
+                for (int q = 0; q < 4; ++q) f[q] = lp_load16_sc1(rs, sg < sg1 ? voff + (unsigned)(sg * 16 + q * 4) * 256u : LP_OOB);
             };
-            auto mma_set = [&](int sg, const u32x4 (&f)[4]) {
-                if (sg >= nsg) return;
+            auto mma_set = [&](int sg, const u32x4 (&f)[4], f32x4 (&c)[2]) {
+                if (sg >= sg1) return;
+                // all eight W fragments of the set are requested from LDS before the first wait for dZ: one fragment
+                // read per MFMA, issued behind the MFMA before it, left the LDS latency in the chain 128 times a step
+                bf16x8 bfr[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ch = sg * 16 + q * 4 + (lane >> 4);
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, f[q]);
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
                         const int n = tn * 16 + (lane & 15);
-                        const bf16x8 bfr = *(const bf16x8*)(Wl + (long long)n * Gp + lp_wswz(n, ch, 15) * 8);
-                        acc[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af, acc[tn], 0, 0, 0);
+                        bfr[q][tn] = *(const bf16x8*)(Wl + (long long)n * Gp + lp_wswz(n, ch, 15) * 8);
                     }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, f[q]);
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) c[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[q][tn], af, c[tn], 0, 0, 0);
                 }
             };
             // LB_NS fragment sets (LB_NS x 4 KB per wave) in flight: the loads come through the fabric
-            // (sc1), so the bytes in flight per CU set the rate.  Sets beyond nsg are OOB loads (zeros).
+            // (sc1), so the bytes in flight per CU set the rate.  Sets beyond sg1 are OOB loads (zeros).
+            // The K range is summed in FOUR parts, each into an accumulator of its own, in every form of the
+            // kernel (see lb_part): the stream of loads runs on across the part boundaries.
             u32x4 f[LB_NS][4];
+            f32x4 c[4][2];
 #pragma unroll
-            for (int i = 0; i < LB_NS; ++i) load_set(i, f[i]);
+            for (int i = 0; i < LB_NS; ++i) load_set(sg0 + i, f[i]);
+            static_for<4>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                c[P][0] = c[P][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int lo = max(lb_part(P, nsg), sg0), hi = min(lb_part(P + 1, nsg), sg1r);
 #pragma nounroll
-            for (int sg = 0; sg < nsg; sg += LB_NS) {
+                for (int sg = lo; sg < hi; sg += LB_NS) {
 #pragma unroll
-                for (int i = 0; i < LB_NS; ++i) {
-                    mma_set(sg + i, f[i]);
-                    load_set(sg + LB_NS + i, f[i]);
+                    for (int i = 0; i < LB_NS; ++i) {
+                        mma_set(sg + i, f[i], c[P]);
+                        load_set(sg + LB_NS + i, f[i]);
+                    }
                 }
+            });
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) acc[tn] = (c[0][tn] + c[1][tn]) + (c[2][tn] + c[3][tn]);
             }
+            if (KS) {
+                // partial dh of the helper waves -> the block's owner.  A wave's parts it did not run are zero, so with
+                // two waves per block the owner holds p0 + p1 and receives p2 + p3, with four it holds p0 and receives
+                // p1, p2, p3: the same tree either way
+                f32x4* red = (f32x4*)(lp_lds + (size_t)LB_BN * Gp * 2 + 16);
+                if (kq > 0) {
+                    red[((wave - sb) * 2 + 0) * 64 + lane] = acc[0];
+                    red[((wave - sb) * 2 + 1) * 64 + lane] = acc[1];
+                }
+                __syncthreads();
+                if (kq == 0) {
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const f32x4 r1 = red[((sblk) * 2 + tn) * 64 + lane];
+                        if (ks == 2) {
+                            acc[tn] = acc[tn] + r1;
+                        } else {
+                            const f32x4 r2 = red[((sb + sblk) * 2 + tn) * 64 + lane], r3 = red[((2 * sb + sblk) * 2 + tn) * 64 + lane];
+                            acc[tn] = (acc[tn] + r1) + (r2 + r3);
+                        }
+                    }
+                }
             }
         }
         LB_PROF_ACC

@@ -418,29 +418,41 @@ bool persist_fits(const void* kernel, size_t lds, int grid, int threads) {
     const int per_cu = kernel_per_cu(kernel, lds, threads);
     return per_cu >= 1 && grid <= per_cu * device_cus();
 }
+// Sentence tile and kernel form of a persistent recurrence: tiles below 128 sentences (small batches) run the split
+// forms of the kernels (lstm_persist.hpp: MS / KS), which need a little LDS for the partial sums.
+struct PersistPlan { int bm; bool split; const void* kernel; size_t lds; };
 // forward recurrence: half-width workgroups, two per CU
-int lstm_fwd_bm(const Shape& s) {
-    const int per_cu = kernel_per_cu((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), 256);
-    return lstm_fwd_tile(s.B, s.Gp, (per_cu < 1 ? 1 : per_cu) * device_cus());
+PersistPlan lstm_fwd_plan(const Shape& s) {
+    const size_t lds_ms = lstm_fwd2_lds_bytes(s.Hp);
+    const int per_cu = kernel_per_cu((const void*)k_lstm_fwd_persist2<true>, lds_ms, 256);
+    const int bm = lstm_fwd_tile(s.B, s.Gp, (per_cu < 1 ? 1 : per_cu) * device_cus());
+    if (bm < LF_BM) return PersistPlan{bm, true, (const void*)k_lstm_fwd_persist2<true>, lds_ms};
+    return PersistPlan{LF_BM, false, (const void*)k_lstm_fwd_persist2<false>, lstm_fwd2_lds_bytes(s.Hp)};
 }
 bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
     if (s.Hp > 32 * LF_KS_MAX || s.Hp % 32 != 0 || s.Gp % LF_BN != 0) return false;
     if (lstm_fwd_xchg_bytes(s.B, s.Hp) >= (1ull << 31)) return false;
     // groups padded to a multiple of 8 (one XCD per group, see the kernel) when that still fits
-    const int groups = 2 * ceil_div(s.B, lstm_fwd_bm(s)), ctiles = s.Gp / LF_BN;
+    const PersistPlan p = lstm_fwd_plan(s);
+    const int groups = 2 * ceil_div(s.B, p.bm), ctiles = s.Gp / LF_BN;
     *grid = ceil_to(groups, 8) * ctiles;
-    if (persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256)) return true;
+    if (persist_fits(p.kernel, p.lds, *grid, 256)) return true;
     *grid = groups * ctiles;
-    return persist_fits((const void*)k_lstm_fwd_persist2, lstm_fwd2_lds_bytes(s.Hp), *grid, 256);
+    return persist_fits(p.kernel, p.lds, *grid, 256);
+}
+PersistPlan lstm_bwd_plan(const Shape& s) {
+    const int bm = lstm_bwd_tile(s.B, s.Hp, device_cus());
+    if (bm < LB_BM) return PersistPlan{bm, true, (const void*)k_lstm_bwd_persist<true>, lstm_bwd_persist_lds_bytes(s.Gp) + LB_RED_BYTES};
+    return PersistPlan{LB_BM, false, (const void*)k_lstm_bwd_persist<false>, lstm_bwd_persist_lds_bytes(s.Gp)};
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;
-    const int bm = lstm_bwd_tile(s.B, s.Hp, device_cus());
-    const int groups = 2 * ceil_div(s.B, bm), ctiles = s.Hp / LB_BN;
+    const PersistPlan p = lstm_bwd_plan(s);
+    const int groups = 2 * ceil_div(s.B, p.bm), ctiles = s.Hp / LB_BN;
     *grid = ceil_to(groups, 8) * ctiles;
-    if (persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512)) return true;
+    if (persist_fits(p.kernel, p.lds, *grid, 512)) return true;
     *grid = groups * ctiles;
-    return persist_fits((const void*)k_lstm_bwd_persist, lstm_bwd_persist_lds_bytes(s.Gp), *grid, 512);
+    return persist_fits(p.kernel, p.lds, *grid, 512);
 }
 // fp16 activated gates (SAD_WS_GA) are written by the persistent forward recurrence and read by the
 // persistent BPTT: used when both run (same decision in sad_forward and sad_backward as long as the
@@ -673,12 +685,13 @@ int run_lstm_fwd(const Ctx& c) {
     const bf16raw* whh = at<bf16raw>(c.packed, c.pl.whh);
     int pgrid = 0;
     if (lstm_fwd_persist_fits(s, &pgrid)) {
-        hipLaunchKernelGGL(k_lstm_fwd_persist2, dim3(pgrid), dim3(256), lstm_fwd2_lds_bytes(s.Hp), c.st, s, lens, whh, G, Cs,
-                           Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
+        const PersistPlan plan = lstm_fwd_plan(s);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(plan.split ? k_lstm_fwd_persist2<true> : k_lstm_fwd_persist2<false>), dim3(pgrid), dim3(256),
+                           plan.lds, c.st, s, lens, whh, G, Cs, Hs, at<bf16raw>(c.ws, c.wl.off[SAD_WS_HX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
                            (c.upper || !g_withhold_upper_only.load(std::memory_order_relaxed)) ? g_withhold_fwd.load(std::memory_order_relaxed) : -1,
-                           lstm_fwd_bm(s), hostflag_dev(), ga_preact(s) ? 1 : 0);
+                           plan.bm, hostflag_dev(), ga_preact(s) ? 1 : 0);
     } else {
         for (int step = 0; step < s.T; ++step) {
             if (s.B >= 512) {
@@ -802,13 +815,13 @@ int run_lstm_bwd(const Ctx& c, const bf16raw* dhs = nullptr, int ldh = 0) {
     const bf16raw* whhT = at<bf16raw>(c.packed, c.pl.whhT);
     int pgrid = 0;
     if (lstm_bwd_persist_fits(s, &pgrid)) {
-        hipLaunchKernelGGL(k_lstm_bwd_persist, dim3(pgrid), dim3(512), lstm_bwd_persist_lds_bytes(s.Gp), c.st, s, lens, whhT, G,
-                           Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
+        const PersistPlan plan = lstm_bwd_plan(s);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(plan.split ? k_lstm_bwd_persist<true> : k_lstm_bwd_persist<false>), dim3(pgrid), dim3(512),
+                           plan.lds, c.st, s, lens, whhT, G, Cs, DHFIN, DZ, at<bf16raw>(c.ws, c.wl.off[SAD_WS_DZX]),
                            half_gates(s) ? at<unsigned short>(c.ws, c.wl.off[SAD_WS_GA]) : (const unsigned short*)nullptr,
                            at<unsigned>(c.ws, c.wl.off[SAD_WS_SYNC]), g_spin_limit.load(std::memory_order_relaxed),
                            (c.upper || !g_withhold_upper_only.load(std::memory_order_relaxed)) ? g_withhold_bwd.load(std::memory_order_relaxed) : -1,
-                           dhs, ldh, lstm_bwd_tile(s.B, s.Hp, device_cus()),
-                           hostflag_dev());
+                           dhs, ldh, plan.bm, hostflag_dev());
     } else {
         for (int step = 0; step < s.T; ++step) {
             typedef CfgStepBwd C;

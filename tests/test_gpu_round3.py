@@ -257,3 +257,50 @@ def test_weight_gradients_atomic_fallback_matches_slab_path(V):
         for g in outs:
             assert relerr(g[k], b["grads"][k]) < 2e-2, k
         assert relerr(outs[0][k], outs[1][k]) < 1e-5, k          # same products, different summation order only
+
+
+def test_recurrence_tile_forms_give_the_same_bits():
+    """The persistent recurrences pick their sentence tile from the batch size (128, 64 or 32 sentences; the small tiles
+    run the split forms of the kernels: one 16-sentence block per wave in the forward, the K range of the BPTT shared
+    by several waves and summed in the canonical four parts).  A sentence must come out the same whatever form its
+    batch selects: hidden states, cell states and dZ of a slice of the batch, run on its own, are BIT-identical to the
+    same sentences inside the full batch (B = 1024 -> tile 128; 512 -> 64; 256, 64 and a ragged 33 -> 32)."""
+    import torch
+    from sad_amd import functional as Fn
+    B, T, V, E, H = 1024, 24, 500, 300, 512
+    dev = torch.device("cuda:0")
+    Fn.KEEP_LAST = True
+    lengths = synth.make_lengths(B, T, seed=9)
+    params = synth.make_params(V, E, H, seed=4)
+    pw = Fn.pack_weights({k: torch.from_numpy(v).to(dev) for k, v in params.items()})
+    # one-hot soft tokens: the embedded tokens are exact whatever split of the vocabulary range a batch size selects in K1
+    ids = torch.from_numpy(synth.make_token_ids(B, T, V, lengths, seed=6)).to(dev)
+    S = torch.zeros((B, T, V), dtype=torch.bfloat16, device=dev)
+    S.scatter_(2, ids.unsqueeze(2), 1.0)
+    ln = torch.from_numpy(lengths)
+    mask0 = torch.from_numpy(synth.transfer_mask(lengths, T)).to(dev)
+    lab = torch.from_numpy(synth.make_labels(B, seed=2)).to(dev)
+
+    def run(lo, hi):
+        b = hi - lo
+        Sg = S[lo:hi].clone().requires_grad_(True)
+        loss, logits, weights = Fn.discriminator_loss(Sg, ln[lo:hi], mask0[lo:hi].clone(), lab[lo:hi], pw)
+        ws = Fn._Discriminator.last_workspace
+        (loss.sum() / B).backward()
+        torch.cuda.synchronize()
+        ws.check()
+        live = (ws.view("NEED", torch.uint8).reshape(T, b) & 1).bool()
+        # rows of padded steps are never written: whatever an earlier user of the workspace left there (NaN included)
+        zero = torch.zeros((), device=dev)
+        hs = torch.where(live[:, :, None], ws.view("HS", torch.bfloat16).reshape(T, b, -1).float(), zero)
+        cs = torch.where(live[:, :, None], ws.view("CS", torch.float32).reshape(T, b, -1), zero)
+        dz = ws.view("DZ", torch.bfloat16).reshape(T, b, -1).float()
+        return dict(logits=logits.detach().clone(), Hs=hs.clone(), Cs=cs.clone(), DZ=dz.clone())
+
+    full = run(0, B)
+    assert float(full["DZ"].abs().sum()) > 0
+    for lo, hi in ((0, 512), (512, 1024), (256, 512), (64, 128), (991, 1024)):
+        part = run(lo, hi)
+        assert torch.equal(part["logits"], full["logits"][lo:hi]), (lo, hi)
+        for name in ("Hs", "Cs", "DZ"):
+            assert torch.equal(part[name], full[name][:, lo:hi]), (lo, hi, name)

@@ -299,17 +299,20 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
             auto load_set = [&](auto slot, int sg) {
                 constexpr int S = decltype(slot)::value;
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
+                    for (int tm = 0; tm < TM; ++tm)
                         a[S][tm][kk] = lp_load16_sc1(rs, sg * 4 + kk < nks ? voff[tm] + (unsigned)(sg * 4 + kk) * 1024u : LP_OOB);
+                    __builtin_amdgcn_sched_barrier(0);   // issue order = use order: the waits stay counted
+                }
             };
             auto mma_set = [&](auto slot, int sg) {
                 constexpr int S = decltype(slot)::value;
+                if (sg >= nsets) return;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    if (sg * 4 + kk < nks) {
-                        const int ch = (sg * 4 + kk) * 4 + q;
+                    {
+                        const int ch = min((sg * 4 + kk) * 4 + q, cpr - 1);
                         bf16x8 bfr[4];
 #pragma unroll
                         for (int tn = 0; tn < 4; ++tn) {

@@ -32,6 +32,10 @@ namespace sad {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
+// the workgroup's "a wait timed out" flag lives in LDS and is read through an LDS pointer: through a generic pointer it
+// is a FLAT load, which counts as a vector-memory operation too -- every read of the flag was a wait for all of the
+// wave's outstanding global loads and stores (in front of the poll, and in front of the hand-off stores)
+typedef volatile __attribute__((address_space(3))) unsigned lds_flag;
 #define SAD_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // 16-byte sc1 (L1-bypassing, agent-coherent) load through a buffer descriptor: visible to the
@@ -61,11 +65,15 @@ __device__ __forceinline__ u32x4 lp_load16_sc1(__amdgpu_buffer_rsrc_t r, unsigne
     return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
 }
 
-// 1: poll the group counter with a scalar load (see lp_counter).  Measured (round 3): correct, and no faster -- forward
-// 231 us either way, BPTT 330 -> 338 us, B = 64 0.342 -> 0.356 ms: the waves' first fragment wait stands behind the same
-// older operations the vector poll stood behind.  Kept as a build switch.
-#ifndef SAD_SCALAR_POLL
-#define SAD_SCALAR_POLL 0
+// 1: poll the group counter with a scalar load when the group sits on one XCD (see lp_counter).  Measured twice in
+// round 3, correct both times and never faster than the vector poll beyond the noise (forward 231 us either way before
+// the gate records were kept raw across the K loop, 203-206 against 205-207 us after; BPTT 330 -> 338 us).  Build
+// switches, off: the vector poll does not depend on where the workgroups of a group are placed.
+#ifndef SAD_SCALAR_POLL_FWD
+#define SAD_SCALAR_POLL_FWD 0
+#endif
+#ifndef SAD_SCALAR_POLL_BWD
+#define SAD_SCALAR_POLL_BWD 0
 #endif
 constexpr int LP_BM = 128;                                   // sentences per tile (= LF_BM = LB_BM)
 constexpr int LP_SYNC_PITCH = 32;                            // counter pitch in 4-byte words (128-B lines)
@@ -98,7 +106,7 @@ __device__ __forceinline__ unsigned lp_counter(gu32* counter, bool scalar) {
     return __hip_atomic_load(counter, SAD_RLX_AGENT);
 }
 __device__ __forceinline__ void lp_wait(gu32* counter, unsigned target, unsigned spin_limit, gu32* errword,
-                                        volatile unsigned* dead, unsigned* hostflag, unsigned code, bool scalar = false) {
+                                        lds_flag* dead, unsigned* hostflag, unsigned code, bool scalar = false) {
     if (*dead) return;
     unsigned spins = 0;
     while (lp_counter(counter, scalar) < target) {
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
     }
     int maxlen = 0;
-    volatile unsigned* dead = (volatile unsigned*)(lp_lds + (size_t)LF_BN * Hp * 2 + 4);   // a wait timed out
+    lds_flag* dead = (lds_flag*)(lp_lds + (size_t)LF_BN * Hp * 2 + 4);   // a wait timed out
     {
         int* red_max = (int*)(lp_lds + (size_t)LF_BN * Hp * 2);
         if (tid == 0) { *red_max = 0; *dead = 0u; }
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
     }
     const int nks = Hp / 32;
     const int nsets = (nks + 3) / 4;
+    const bool spoll = xcd_local && SAD_SCALAR_POLL_FWD;
     unsigned done = 0;
     LF_PROF_DECL
 
@@ -261,18 +270,22 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         // accumulators start from the gate pre-activations of this step (private to the workgroup,
         // independent of h: issued before the wait)
         f32x4 acc[TM][4];
+        u32x4 praw[TM][2];
         bool act[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             act[tm] = blen[tm] > t;
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[tm][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            praw[tm][0] = praw[tm][1] = u32x4{0u, 0u, 0u, 0u};
             if (act[tm]) {
                 if (ga_pre) {
                     // the in-projection left the pre-activations as fp16 records in GA, in this lane's own record
-                    // (the activated gates overwrite it below): 32 bytes instead of 64 of fp32 G
+                    // (the activated gates overwrite it below): 32 bytes instead of 64 of fp32 G.  Kept raw until
+                    // the K loop is over: unpacking here is a wait for these loads in front of the hand-off wait
                     const unsigned short* ga = GA + ga_index(t, dir, brow[tm], j, B, Hp);
-                    ga_unpack(*(const u32x4*)ga, *(const u32x4*)(ga + 8), acc[tm][0], acc[tm][1], acc[tm][2], acc[tm][3]);
+                    praw[tm][0] = *(const u32x4*)ga;
+                    praw[tm][1] = *(const u32x4*)(ga + 8);
                 } else {
                     const float* g = G + ((long long)t * B + brow[tm]) * s.Gld + dir * Gp + n0 + u4;
 #pragma unroll
@@ -282,7 +295,11 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
         }
         LF_PROF_T(0)
         if (done > 0) {
-            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 1u, xcd_local && SAD_SCALAR_POLL);
+            // vector poll: its result is waited for with vmcnt, in order behind the record loads anyway.  EVERY wave waits
+            // for its records here, in front of the barrier (measured: with only the polling wave waiting, 236 us at cfg3
+            // against 205 us)
+            if (ga_pre && !spoll) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 1u, spoll);
             LF_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no code motion across the poll
             __syncthreads();
@@ -341,6 +358,15 @@ __global__ __launch_bounds__(256, 2) void k_lstm_fwd_persist2(Shape s, const int
                     load_set(sl, sg + NS + I);
                 });
             }
+            }
+        }
+        if (ga_pre) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                f32x4 p[4];
+                ga_unpack(praw[tm][0], praw[tm][1], p[0], p[1], p[2], p[3]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[tm][g] += p[g];
             }
         }
         LF_PROF_ACC
@@ -542,7 +568,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         }
     }
     int maxlen = 0;
-    volatile unsigned* dead = (volatile unsigned*)(lp_lds + (size_t)LB_BN * Gp * 2 + 4);   // a wait timed out
+    lds_flag* dead = (lds_flag*)(lp_lds + (size_t)LB_BN * Gp * 2 + 4);   // a wait timed out
     {
         int* red_max = (int*)(lp_lds + (size_t)LB_BN * Gp * 2);
         if (tid == 0) { *red_max = 0; *dead = 0u; }
@@ -627,7 +653,7 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         LB_PROF_T(0)
         if (done > 0) {
-            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 2u, xcd_local && SAD_SCALAR_POLL);
+            if (tid == 0) lp_wait(counter, done * (unsigned)ctiles, spin_limit, errword, dead, hostflag, 2u, xcd_local && SAD_SCALAR_POLL_BWD);
             LB_PROF_T(1)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __syncthreads();

@@ -33,8 +33,18 @@ _LIVE_PARAMS = (
 _RNN_PARAMS = _LIVE_PARAMS[1:9]      # the eight rnn.* tensors: all a layer above the first owns
 
 
+def _raw_stream_fallback(index):
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", _raw_stream_fallback)
+
+
 def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw stream of the current device straight from the C layer: torch.cuda.current_stream() resolves its default
+    # device through torch.cuda.is_available(), which reads the environment on every call (measured on the GPU box:
+    # the longest single item of the module path's host time at batch 64)
+    return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
 
 
 _NULL_CTX = contextlib.nullcontext()

@@ -26,8 +26,18 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _raw_stream_fallback(index):
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", _raw_stream_fallback)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw stream of the current device straight from the C layer: torch.cuda.current_stream() resolves its default
+    # device through torch.cuda.is_available(), which reads the environment on every call (measured on the GPU box:
+    # the longest single item of the module path's host time at batch 64)
+    return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
 
 
 def _kind(dtype):

@@ -483,6 +483,8 @@ __host__ __device__ inline int lstm_bwd_tile(int B, int Hp, int cus) {
 __host__ __device__ inline size_t lstm_bwd_persist_lds_bytes(int Gp) { return (size_t)LB_BN * Gp * 2 + 16; }
 // K-split form (tiles of 32 / 64 sentences): partial dh of up to 6 helper waves, 2 x f32x4 per lane
 constexpr size_t LB_RED_BYTES = 6 * 2 * 64 * 16;
+// wave-private strip of the row-major dZ copy: 16 sentences x (128 + 16) bytes
+constexpr size_t LB_STRIP_BYTES = 16 * 144;
 // Hand-off image of dZ between the workgroups of a group, two step parities: laid out so that the 16
 // lanes of a quarter wave (16 sentences, one 8-column chunk = one MFMA fragment piece each) touch 256
 // contiguous bytes -- fragments loaded straight from the row-major DZ touched 16 cache lines per
@@ -584,6 +586,12 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
     const int rlen = (sblk * 16 < bm && b < B) ? lens[b] : 0;   // K loop: every wave of the block
     const bool mine = kq == 0 && sblk * 16 < bm && b < B;        // owner of the sentence: operands, derivatives, stores
     const int len = mine ? rlen : 0;
+    int len8[2];                                                 // the row-major copy's lane -> sentence mapping (8 lanes a row)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b8 = b0 + sblk * 16 + 8 * i + (lane >> 3);
+        len8[i] = (kq == 0 && sblk * 16 < bm && b8 < B) ? lens[b8] : 0;
+    }
     int ju[2], pcu[2];
     f32x4 dcreg[2];
 #pragma unroll
@@ -808,8 +816,9 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, SAD_RLX_AGENT);
         ++done;
-        if (act && SAD_LB_ABL != 1) {
-            // row-major copy for the kernels after the recurrence: not part of the hand-off, plain stores
+        const bool act_t_copy = act;
+        if (KS && act_t_copy && SAD_LB_ABL != 1) {
+            // small tiles: straight from the registers (few rows per workgroup; the LDS turn below costs more than it saves)
             bf16raw* zout = DZ + ((long long)t * B + b) * Ncat + (long long)dir * Gp;
             const int q = lane >> 4;
 #pragma unroll
@@ -817,6 +826,29 @@ __global__ __launch_bounds__(512) void k_lstm_bwd_persist(Shape s, const int* __
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2)
                     *(u32x4*)&zout[(pcu[tn] - 4 * q) + (2 * p2 + (q & 1)) * 16 + (q >> 1) * 8] = pv[tn][p2];
+        }
+        if (!KS && SAD_LB_ABL != 1) {
+            // row-major copy for the kernels after the recurrence: not part of the hand-off, plain stores.  A sentence's
+            // 256 bytes sit in the registers of its four lanes, 64 bytes per (tn, p2): stored from there, a wave
+            // instruction touches 16 rows x half a line, and these stores stand in the vector-memory queue in front of
+            // the next step's operand loads (without the copy the launch runs 295 us instead of 327).  Through a
+            // wave-private LDS strip (pitch 128 + 16 bytes: both sides conflict-free) the wave turns each tn half into
+            // two stores of 8 rows x one whole line: 324 -> 312 us at cfg3.
+            unsigned char* strip = lp_lds + (size_t)LB_BN * Gp * 2 + 16 + (size_t)wave * LB_STRIP_BYTES;
+            const int q = lane >> 4, srow = lane & 15;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2)
+                    *(u32x4*)(strip + srow * 144 + (p2 * 4 + (q & 1) * 2 + (q >> 1)) * 16) = pv[tn][p2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int s2 = 8 * i + (lane >> 3), pc = lane & 7;
+                    const u32x4 v = *(const u32x4*)(strip + s2 * 144 + pc * 16);
+                    if (len8[i] > t)
+                        *(u32x4*)&DZ[((long long)t * B + b0 + sblk * 16 + s2) * Ncat + (long long)dir * Gp + ((j0 >> 4) + tn) * 64 + pc * 8] = v;
+                }
+            }
         }
         LB_PROF_T(6)
         LB_PROF_END

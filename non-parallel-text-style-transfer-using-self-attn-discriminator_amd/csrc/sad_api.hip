@@ -443,7 +443,7 @@ bool lstm_fwd_persist_fits(const Shape& s, int* grid) {
 PersistPlan lstm_bwd_plan(const Shape& s) {
     const int bm = lstm_bwd_tile(s.B, s.Hp, device_cus());
     if (bm < LB_BM) return PersistPlan{bm, true, (const void*)k_lstm_bwd_persist<true>, lstm_bwd_persist_lds_bytes(s.Gp) + LB_RED_BYTES};
-    return PersistPlan{LB_BM, false, (const void*)k_lstm_bwd_persist<false>, lstm_bwd_persist_lds_bytes(s.Gp)};
+    return PersistPlan{LB_BM, false, (const void*)k_lstm_bwd_persist<false>, lstm_bwd_persist_lds_bytes(s.Gp) + 8 * LB_STRIP_BYTES};
 }
 bool lstm_bwd_persist_fits(const Shape& s, int* grid) {
     if (s.Gp > 128 * LB_SG_MAX || s.Hp % LB_BN != 0 || (long long)s.B * s.Ncat * 2 >= (1ll << 31)) return false;

@@ -304,3 +304,24 @@ def test_recurrence_tile_forms_give_the_same_bits():
         assert torch.equal(part["logits"], full["logits"][lo:hi]), (lo, hi)
         for name in ("Hs", "Cs", "DZ"):
             assert torch.equal(part[name], full[name][:, lo:hi]), (lo, hi, name)
+
+
+def test_ragged_large_batch_full_tile_forms_vs_oracle():
+    """B = 700 at H = 512: both recurrences run their FULL-tile forms (128 sentences) with a partial sixth tile (60
+    sentences), the BPTT's row-major dZ copy goes through its LDS strip with rows beyond B masked.  Forward, dS and all
+    parameter gradients against the fp64 oracle."""
+    B, T, V, E, H = 700, 8, 300, 300, 512
+    lengths = synth.make_lengths(B, T, seed=B)
+    params = synth.make_params(V, E, H, seed=11)
+    S = synth.make_soft_tokens(B, T, V, lengths, seed=12, kind="dense", time_major=False)
+    labels = synth.make_labels(B, seed=13)
+    mask = synth.transfer_mask(lengths, T)
+    out = run_sad(params, S, lengths, mask, labels, param_grads=True, s_dtype="bf16")
+    p = O.cast_params(params, np.float64)
+    f = O.forward(p, S.astype(np.float64), lengths, mask.copy(), True, labels=labels, guard=True)
+    dl = O.ce_dlogits(f["logits"], labels, np.full((B,), 1.0 / B))
+    b = O.backward(p, f["cache"], dl, want_param_grads=True)
+    errs = dict(logits=relerr(out["logits"], f["logits"]), weights=relerr(out["weights"], f["weights"]), dS=relerr(out["dS"], b["dS"]))
+    for k, w in b["grads"].items():
+        errs["g:" + k] = relerr(out["grads"][k], w, floor=1e-3 if k == "linear_attn.bias" else 1e-12)
+    assert max(errs.values()) < 2e-2, errs
